@@ -1,0 +1,546 @@
+"""CPU oracle for the TT/QTT core-arithmetic hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy/SciPy-LAPACK *restatement* of the reference algorithms of
+TensorTrainNumerics.jl v1.1.3 (Julia).  It exists so the HIP path can be checked;
+it is never part of the shipped product path.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+
+Parity pinning: Julia is not installed in the build container (nothing was denied;
+the runtime is simply absent), so this oracle cannot be compared with the reference
+run live.  It is pinned instead against every closed-form / known-answer test the
+reference's own ``test/`` directory holds for this path (see ``tests/test_oracle_*``
+and SURVEY.md §8c).  Quantities no reference test pins (values of ``tt_compress!``
+on incompressible input, LAPACK sign/gauge choices, the ``truncerr>0`` rank rule
+beyond two loose accuracy checks) are "parity unpinned by the reference" and are
+pinned only against this restatement.
+
+Conventions: a vector core is an ndarray of shape ``(n, r_left, r_right)`` indexed
+``[i, a, b]`` exactly like the reference's ``Array{T,3}`` (physical index first); an
+operator core is ``(n_out, n_in, R_left, R_right)``.  Site numbers in the public
+functions are 1-based like the reference (``orthogonalize(x; i)``,
+``_tt_bond_truncate!(psi, k)``).  All citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import scipy.linalg as sla
+
+__all__ = [
+    "TTvector", "TToperator", "r_and_d_to_rks", "zeros_tt", "zeros_tto", "rand_tt",
+    "toeplitz_to_qtto", "Delta", "shift", "id_tto", "rand_tto", "qtt_sin", "qtt_cos", "qtt_exp",
+    "qtt_polynom", "qtt_to_vector", "ttv_to_tensor", "tto_to_tensor", "qtto_to_matrix",
+    "apply", "dot", "norm", "euclidean_distance", "hadamard", "add", "add_", "scale",
+    "sub", "div", "orthogonalize", "svdtrunc", "svdtrunc_shadowed", "tt_bond_truncate_",
+    "tt_compress_", "copy_tt",
+]
+
+
+# --------------------------------------------------------------------------------------
+# Types — src/tt_tools.jl:23-29 (TTvector), :48-54 (TToperator)
+# --------------------------------------------------------------------------------------
+@dataclass
+class TTvector:
+    N: int
+    ttv_vec: List[np.ndarray]
+    ttv_dims: Tuple[int, ...]
+    ttv_rks: List[int]
+    ttv_ot: List[int]
+
+
+@dataclass
+class TToperator:
+    N: int
+    tto_vec: List[np.ndarray]
+    tto_dims: Tuple[int, ...]
+    tto_rks: List[int]
+    tto_ot: List[int]
+
+
+def copy_tt(x: TTvector) -> TTvector:
+    """Base.copy — src/tt_tools.jl:172-178."""
+    return TTvector(x.N, [c.copy() for c in x.ttv_vec], tuple(x.ttv_dims), list(x.ttv_rks), list(x.ttv_ot))
+
+
+def _prod(xs) -> int:
+    p = 1
+    for v in xs:
+        p *= int(v)
+    return p
+
+
+# --------------------------------------------------------------------------------------
+# r_and_d_to_rks — src/tt_tools.jl:407-425 (loop over eachindex(dims) only; odd zero-dim
+# branches pinned by test/test_tt_tools.jl:945-946)
+# --------------------------------------------------------------------------------------
+def r_and_d_to_rks(rks: Sequence[int], dims: Sequence[int], rmax: int = 1024) -> List[int]:
+    new_rks = [1] * len(rks)
+    for i in range(len(dims)):  # Julia i = i+1
+        q = _prod(dims[i:])       # prod(dims[i:end])
+        p = _prod(dims[:i])       # prod(dims[1:i-1])  (empty product = 1)
+        if q > 0:
+            if p > 0:
+                new_rks[i] = min(int(rks[i]), p, q, rmax)
+            else:
+                new_rks[i] = min(int(rks[i]), q, rmax)
+        else:
+            if p > 0:
+                new_rks[i] = min(int(rks[i]), p, rmax)
+            else:
+                new_rks[i] = min(int(rks[i]), rmax)
+    return new_rks
+
+
+# --------------------------------------------------------------------------------------
+# zeros_tt / zeros_tto — src/tt_operators.jl:548-573, :601-616
+# --------------------------------------------------------------------------------------
+def zeros_tt(dims: Sequence[int], rks: Sequence[int], ot=None) -> TTvector:
+    assert len(dims) + 1 == len(rks), "Dimensions and ranks are not compatible"
+    d = len(dims)
+    vec = [np.zeros((dims[i], rks[i], rks[i + 1])) for i in range(d)]
+    return TTvector(d, vec, tuple(int(v) for v in dims), [int(r) for r in rks],
+                    [0] * d if ot is None else [int(o) for o in ot])
+
+
+def zeros_tt_ndr(n: int, d: int, r: int, r_and_d: bool = True) -> TTvector:
+    """zeros_tt(n::Integer, d::Integer, r; r_and_d=true) — src/tt_operators.jl:560-569."""
+    dims = (n,) * d
+    if r_and_d:
+        rks = r_and_d_to_rks([r] * (d + 1), dims)
+    else:
+        rks = [r] * (d + 1)
+        rks[0], rks[-1] = 1, 1
+    return zeros_tt(dims, rks)
+
+
+def zeros_tto(dims: Sequence[int], rks: Sequence[int]) -> TToperator:
+    assert len(dims) + 1 == len(rks), "Dimensions and ranks are not compatible"
+    d = len(dims)
+    vec = [np.zeros((dims[i], dims[i], rks[i], rks[i + 1])) for i in range(d)]
+    return TToperator(d, vec, tuple(int(v) for v in dims), [int(r) for r in rks], [0] * d)
+
+
+def zeros_tto_ndr(n: int, d: int, r: int) -> TToperator:
+    """zeros_tto(n, d, r) — src/tt_operators.jl:611-616 (ranks capped with dims.^2, rmax=r)."""
+    dims = (n,) * d
+    rks = r_and_d_to_rks([r] * (d + 1), [v * v for v in dims], rmax=r)
+    return zeros_tto(dims, rks)
+
+
+# --------------------------------------------------------------------------------------
+# rand_tt — src/tt_tools.jl:100-139.  The reference draws ``randn``; the oracle takes the
+# standard-normal source as an argument so tests can hand identical bits to the HIP path.
+# --------------------------------------------------------------------------------------
+def rand_tt(dims: Sequence[int], rks, rng: np.random.Generator) -> TTvector:
+    d = len(dims)
+    if isinstance(rks, (int, np.integer)):
+        rmax = int(rks)
+        rks = r_and_d_to_rks([rmax] * (d + 1), dims, rmax=rmax)  # :134-139
+    y = zeros_tt(dims, rks)
+    for i in range(d):
+        y.ttv_vec[i] = rng.standard_normal((dims[i], rks[i], rks[i + 1]))  # :122
+    return y
+
+
+def rand_tto(dims: Sequence[int], rmax: int, rng: np.random.Generator) -> TToperator:
+    """rand_tto — src/tt_operators.jl:534-545."""
+    d = len(dims)
+    rks = [1] * (d + 1)
+    vec = []
+    for i in range(d):
+        ri = min(_prod(dims[:i]), _prod(dims[i:]), rmax)
+        rip = min(_prod(dims[: i + 1]), _prod(dims[i + 1:]), rmax)
+        rks[i + 1] = rip
+        vec.append(rng.standard_normal((dims[i], dims[i], ri, rip)))
+    return TToperator(d, vec, tuple(dims), rks, [0] * d)
+
+
+# --------------------------------------------------------------------------------------
+# Operator constructors — src/tt_operators.jl:4-19 (toeplitz_to_qtto), :24 (shift),
+# :283-285 (Δ), :519-532 (id_tto)
+# --------------------------------------------------------------------------------------
+def toeplitz_to_qtto(alpha: float, beta: float, gamma: float, d: int) -> TToperator:
+    out = zeros_tto_ndr(2, d, 3)
+    Id = np.eye(2)
+    J = np.zeros((2, 2))
+    J[0, 1] = 1.0
+    for i in range(2):
+        for j in range(2):
+            out.tto_vec[0][i, j, 0, :] = [Id[i, j], J[j, i], J[i, j]]
+            for k in range(1, d - 1):
+                out.tto_vec[k][i, j, :, :] = [[Id[i, j], J[j, i], J[i, j]],
+                                              [0.0, J[i, j], 0.0],
+                                              [0.0, 0.0, J[j, i]]]
+            out.tto_vec[d - 1][i, j, :, 0] = [alpha * Id[i, j] + beta * J[i, j] + gamma * J[j, i],
+                                              gamma * J[i, j],
+                                              beta * J[j, i]]
+    return out
+
+
+def Delta(d: int) -> TToperator:
+    return toeplitz_to_qtto(2, -1, -1, d)
+
+
+def shift(d: int) -> TToperator:
+    return toeplitz_to_qtto(0, 1, 0, d)
+
+
+def id_tto(d: int, n_dim: int = 2) -> TToperator:
+    # note: cores are always 2x2 regardless of n_dim (src/tt_operators.jl:528-529)
+    dims = (n_dim,) * d
+    vec = [np.eye(2).reshape(2, 2, 1, 1).copy() for _ in range(d)]
+    return TToperator(d, vec, dims, [1] * (d + 1), [0] * d)
+
+
+# --------------------------------------------------------------------------------------
+# Analytic QTT vectors — src/qtt_tools.jl:88-110 (polynom), :116-132 (cos), :138-154 (sin),
+# :159-175 (exp)
+# --------------------------------------------------------------------------------------
+def qtt_sin(d: int, a: float = 0.0, b: float = 1.0, lam: float = 1.0) -> TTvector:
+    out = zeros_tt_ndr(2, d, 2)
+    h = (b - a) / (2 ** d - 1)
+    t1 = a
+    out.ttv_vec[0][0, 0, :] = [math.sin(lam * math.pi * t1), math.cos(lam * math.pi * t1)]
+    t1 = a + h * 2 ** (d - 1)
+    out.ttv_vec[0][1, 0, :] = [math.sin(lam * math.pi * t1), math.cos(lam * math.pi * t1)]
+    for k in range(2, d):  # Julia k = 2:(d-1)
+        out.ttv_vec[k - 1][0, :, :] = [[1.0, 0.0], [0.0, 1.0]]
+        tk = h * 2 ** (d - k)
+        c, s = math.cos(lam * math.pi * tk), math.sin(lam * math.pi * tk)
+        out.ttv_vec[k - 1][1, :, :] = [[c, -s], [s, c]]
+    out.ttv_vec[d - 1][0, 0, 0] = 1.0
+    td = h
+    out.ttv_vec[d - 1][1, :, 0] = [math.cos(lam * math.pi * td), math.sin(lam * math.pi * td)]
+    return out
+
+
+def qtt_cos(d: int, a: float = 0.0, b: float = 1.0, lam: float = 1.0) -> TTvector:
+    out = zeros_tt_ndr(2, d, 2)
+    h = (b - a) / (2 ** d - 1)
+    t1 = a
+    out.ttv_vec[0][0, 0, :] = [math.cos(lam * math.pi * t1), -math.sin(lam * math.pi * t1)]
+    t1 = a + h * 2 ** (d - 1)
+    out.ttv_vec[0][1, 0, :] = [math.cos(lam * math.pi * t1), -math.sin(lam * math.pi * t1)]
+    for k in range(2, d):
+        out.ttv_vec[k - 1][0, :, :] = [[1.0, 0.0], [0.0, 1.0]]
+        tk = h * 2 ** (d - k)
+        c, s = math.cos(lam * math.pi * tk), math.sin(lam * math.pi * tk)
+        out.ttv_vec[k - 1][1, :, :] = [[c, -s], [s, c]]
+    out.ttv_vec[d - 1][0, 0, 0] = 1.0
+    td = h
+    out.ttv_vec[d - 1][1, :, 0] = [math.cos(lam * math.pi * td), math.sin(lam * math.pi * td)]
+    return out
+
+
+def qtt_exp(d: int, a: float = 0.0, b: float = 1.0, alpha: float = 1.0, beta: float = 0.0) -> TTvector:
+    out = zeros_tt_ndr(2, d, 1)
+    h = (b - a) / (2 ** d - 1)
+    out.ttv_vec[0][0, 0, 0] = math.exp(alpha * a + beta)
+    out.ttv_vec[0][1, 0, 0] = math.exp(alpha * (a + h * 2 ** (d - 1)) + beta)
+    for k in range(2, d):
+        tk = h * 2 ** (d - k)
+        out.ttv_vec[k - 1][0, 0, 0] = 1.0
+        out.ttv_vec[k - 1][1, 0, 0] = math.exp(alpha * tk)
+    out.ttv_vec[d - 1][0, 0, 0] = 1.0
+    out.ttv_vec[d - 1][1, 0, 0] = math.exp(alpha * h)
+    return out
+
+
+def qtt_polynom(coef: Sequence[float], d: int, a: float = 0.0, b: float = 1.0) -> TTvector:
+    p = len(coef)
+    h = (b - a) / (2 ** d - 1)
+    out = zeros_tt_ndr(2, d, p, r_and_d=False)
+
+    def phi(x, s):
+        return sum(coef[k] * x ** (k - s) * math.comb(k, s) for k in range(s, p))
+
+    t1 = a
+    out.ttv_vec[0][0, 0, :] = [phi(t1, k) for k in range(p)]
+    t1 = a + h * 2 ** (d - 1)
+    out.ttv_vec[0][1, 0, :] = [phi(t1, k) for k in range(p)]
+    for k in range(2, d):
+        tk = h * 2 ** (d - k)
+        for j in range(p):
+            out.ttv_vec[k - 1][0, j, j] = 1.0
+            for i in range(p):
+                # Julia: binomial(i, i-j) is 0 for i<j
+                out.ttv_vec[k - 1][1, i, j] = (math.comb(i, i - j) * tk ** (i - j)) if i >= j else 0.0
+    out.ttv_vec[d - 1][0, 0, 0] = 1.0
+    td = h
+    out.ttv_vec[d - 1][1, :, 0] = [td ** k for k in range(p)]
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Densifiers used by the reference tests as their oracle
+#   qtt_to_vector — src/qtt_tools.jl:57-71; ttv_to_tensor — src/tt_tools.jl:265-279;
+#   tto_to_tensor — src/tt_tools.jl:374-392; qtto_to_matrix — src/qtt_tools.jl:180-188
+# --------------------------------------------------------------------------------------
+def qtt_to_vector(qtt: TTvector) -> np.ndarray:
+    P = qtt.ttv_vec[0][:, 0, :]
+    for k in range(1, qtt.N):
+        G = qtt.ttv_vec[k]
+        n_prev = P.shape[0]
+        P_new = np.empty((2 * n_prev, G.shape[2]), dtype=P.dtype)
+        P_new[0::2, :] = P @ G[0, :, :]
+        P_new[1::2, :] = P @ G[1, :, :]
+        P = P_new
+    return P.reshape(-1, order="F")
+
+
+def ttv_to_tensor(x: TTvector) -> np.ndarray:
+    # full tensor T[t1,...,td] = prod_k X_k[t_k,:,:]
+    cur = x.ttv_vec[0][:, 0, :]  # (n1, r1)
+    shape = [x.ttv_dims[0]]
+    for k in range(1, x.N):
+        G = x.ttv_vec[k]
+        cur = np.einsum("pa,iab->pib", cur, G).reshape(-1, G.shape[2])
+        shape.append(x.ttv_dims[k])
+    return cur[:, 0].reshape(shape)
+
+
+def tto_to_tensor(A: TToperator) -> np.ndarray:
+    d = A.N
+    cur = A.tto_vec[0][:, :, 0, :]  # (n, n, R1)
+    cur = cur.reshape(A.tto_dims[0], A.tto_dims[0], -1)
+    # build as [x1..xk, y1..yk, R]
+    T = cur[:, :, :]
+    xs = [A.tto_dims[0]]
+    out = T  # shape (x1, y1, R)
+    for k in range(1, d):
+        G = A.tto_vec[k]  # (n,n,Rl,Rr)
+        out = np.tensordot(out, G, axes=([-1], [2]))  # (..., i, j, Rr)
+        xs.append(A.tto_dims[k])
+    # out has axes (x1,y1,x2,y2,...,xd,yd,Rd); drop last
+    out = out[..., 0]
+    perm = list(range(0, 2 * d, 2)) + list(range(1, 2 * d, 2))
+    return np.transpose(out, perm)
+
+
+def qtto_to_matrix(A: TToperator) -> np.ndarray:
+    d = A.N
+    T = tto_to_tensor(A)
+    # tuple_to_index: site 1 is the most significant bit -> C-order flatten
+    return T.reshape(2 ** d, 2 ** d)
+
+
+# --------------------------------------------------------------------------------------
+# tto * ttv — src/tt_operations.jl:101-111
+# --------------------------------------------------------------------------------------
+def apply(A: TToperator, v: TTvector) -> TTvector:
+    assert tuple(A.tto_dims) == tuple(v.ttv_dims), "Incompatible dimensions"
+    rks = [a * b for a, b in zip(A.tto_rks, v.ttv_rks)]
+    y = zeros_tt(A.tto_dims, rks)
+    for k in range(v.N):
+        Ak, Xk = A.tto_vec[k], v.ttv_vec[k]
+        # Y[i, a' + Rl*nu', a + Rr*nu] (operator index fastest, from the reshape at :106)
+        T = np.einsum("ijab,jcd->icadb", Ak, Xk)
+        y.ttv_vec[k] = T.reshape(Ak.shape[0], Xk.shape[1] * Ak.shape[2], Xk.shape[2] * Ak.shape[3])
+    return y
+
+
+# --------------------------------------------------------------------------------------
+# dot / norm / distances — src/tt_operations.jl:239-250, :452-470
+# --------------------------------------------------------------------------------------
+def dot(A: TTvector, B: TTvector) -> float:
+    assert tuple(A.ttv_dims) == tuple(B.ttv_dims), "TT dimensions are not compatible"
+    M = np.ones((1, 1))
+    for k in range(A.N):
+        # M'[a,b] = sum_{z,al,be} conj(A[z,al,a]) * (B[z,be,b] * M[al,be])
+        T = np.einsum("pq,zqb->zpb", M, B.ttv_vec[k])
+        M = np.einsum("zpa,zpb->ab", np.conj(A.ttv_vec[k]), T)
+    return M[0, 0]
+
+
+def norm(a: TTvector) -> float:
+    s = dot(a, a)
+    v = float(np.real(s))
+    v = 0.0 if v < 0 else v
+    return math.sqrt(v)
+
+
+def euclidean_distance(a: TTvector, b: TTvector) -> float:
+    assert tuple(a.ttv_dims) == tuple(b.ttv_dims), "TT dimensions must match"
+    return math.sqrt(max(float(np.real(dot(a, a) - 2 * np.real(dot(b, a)) + dot(b, b))), 0.0))
+
+
+# --------------------------------------------------------------------------------------
+# hadamard — src/tt_operations.jl:343-361
+# --------------------------------------------------------------------------------------
+def hadamard(x: TTvector, y: TTvector) -> TTvector:
+    assert tuple(x.ttv_dims) == tuple(y.ttv_dims), "Incompatible TT dimensions"
+    d = x.N
+    rks = [x.ttv_rks[k] * y.ttv_rks[k] for k in range(d + 1)]
+    vec = []
+    for k in range(d):
+        n = x.ttv_dims[k]
+        core = np.zeros((n, rks[k], rks[k + 1]))
+        for s in range(n):
+            core[s, :, :] = np.kron(x.ttv_vec[k][s, :, :], y.ttv_vec[k][s, :, :])
+        vec.append(core)
+    return TTvector(d, vec, tuple(x.ttv_dims), rks, [0] * d)
+
+
+# --------------------------------------------------------------------------------------
+# + / add! / scalar * / - / /  — src/tt_operations.jl:10-66, :256-266, :283-295
+# --------------------------------------------------------------------------------------
+def add(x: TTvector, y: TTvector) -> TTvector:
+    assert tuple(x.ttv_dims) == tuple(y.ttv_dims), "Incompatible dimensions"
+    d = x.N
+    rks = [a + b for a, b in zip(x.ttv_rks, y.ttv_rks)]
+    rks[0] = 1
+    rks[d] = 1
+    vec = [np.zeros((x.ttv_dims[k], rks[k], rks[k + 1])) for k in range(d)]
+    rx = x.ttv_rks
+    vec[0][:, :, : rx[1]] = x.ttv_vec[0]
+    vec[0][:, :, rx[1]: rks[1]] = y.ttv_vec[0]
+    for k in range(1, d - 1):
+        vec[k][:, : rx[k], : rx[k + 1]] = x.ttv_vec[k]
+        vec[k][:, rx[k]: rks[k], rx[k + 1]: rks[k + 1]] = y.ttv_vec[k]
+    vec[d - 1][:, : rx[d - 1], :1] = x.ttv_vec[d - 1]
+    vec[d - 1][:, rx[d - 1]: rks[d - 1], :1] = y.ttv_vec[d - 1]
+    return TTvector(d, vec, tuple(x.ttv_dims), rks, [0] * d)
+
+
+def add_(x: TTvector, y: TTvector) -> TTvector:
+    z = add(x, y)
+    x.ttv_vec, x.ttv_rks, x.ttv_ot = z.ttv_vec, z.ttv_rks, z.ttv_ot
+    return x
+
+
+def scale(a: float, A: TTvector) -> TTvector:
+    if a == 0:
+        return zeros_tt(A.ttv_dims, A.ttv_rks)
+    i = next((k for k, o in enumerate(A.ttv_ot) if o == 0), 0)
+    X = [c.copy() for c in A.ttv_vec]
+    X[i] = a * X[i]
+    return TTvector(A.N, X, tuple(A.ttv_dims), list(A.ttv_rks), list(A.ttv_ot))
+
+
+def sub(A: TTvector, B: TTvector) -> TTvector:
+    return add(scale(-1.0, B), A)
+
+
+def div(A: TTvector, a: float) -> TTvector:
+    return scale(1 / a, A)
+
+
+# --------------------------------------------------------------------------------------
+# orthogonalize — src/tt_tools.jl:511-543
+# --------------------------------------------------------------------------------------
+def _lq(T: np.ndarray):
+    """Thin LQ via LAPACK (QR of the transpose): T = L @ Q."""
+    q, r = sla.qr(T.T, mode="economic")
+    return r.T, q.T
+
+
+def orthogonalize(x: TTvector, i: int = 1) -> TTvector:
+    d = x.N
+    assert 1 <= i <= d, "Impossible orthogonalization"
+    dims = x.ttv_dims
+    y_rks = r_and_d_to_rks(x.ttv_rks, dims)
+    y = zeros_tt(dims, y_rks)
+    FR = np.ones((1, 1))
+    for j in range(1, i):  # left sweep, sites 1..i-1
+        y.ttv_ot[j - 1] = 1
+        Xj = x.ttv_vec[j - 1]
+        n = dims[j - 1]
+        yr = y.ttv_rks[j - 1]
+        T = np.einsum("ag,sgb->sab", FR, Xj)           # [s, alpha, beta]; row = alpha + yr*s
+        Q, R = sla.qr(T.reshape(n * yr, Xj.shape[2]), mode="economic")
+        rnew = Q.shape[1]
+        y.ttv_rks[j] = rnew
+        y.ttv_vec[j - 1] = Q.reshape(n, yr, rnew)
+        FR = R[:rnew, :]
+    FL = np.ones((1, 1))
+    for j in range(d, i, -1):  # right sweep, sites d..i+1
+        y.ttv_ot[j - 1] = -1
+        Xj = x.ttv_vec[j - 1]
+        n = dims[j - 1]
+        yr = y.ttv_rks[j]
+        T = np.einsum("sag,gb->asb", Xj, FL)           # [alpha, s, beta]; col = beta + yr*s
+        L, Q = _lq(T.reshape(Xj.shape[1], n * yr))
+        rnew = Q.shape[0]
+        y.ttv_rks[j - 1] = rnew
+        y.ttv_vec[j - 1] = Q.reshape(rnew, n, yr).transpose(1, 0, 2).copy()
+        FL = L[:, :rnew]
+    y.ttv_ot[i - 1] = 0
+    Xi = x.ttv_vec[i - 1]
+    core = np.zeros((dims[i - 1], y.ttv_rks[i - 1], y.ttv_rks[i]))
+    for k in range(dims[i - 1]):
+        core[k, :, :] = FR @ Xi[k, :, :] @ FL
+    y.ttv_vec[i - 1] = core
+    return y
+
+
+# --------------------------------------------------------------------------------------
+# _svdtrunc — the EFFECTIVE method is src/tt_cross_interpolation.jl:149-166 (relative
+# tail-norm rule); src/tt_tools.jl:737-741 is shadowed for every Matrix argument.
+# --------------------------------------------------------------------------------------
+def svdtrunc(A: np.ndarray, max_bond: int = 2 ** 62, truncerr: float = 0.0):
+    U, s, Vt = sla.svd(A, full_matrices=False, lapack_driver="gesdd")
+    r = len(s)
+    if truncerr > 0:
+        nrm = float(np.linalg.norm(s))
+        cum = 0.0
+        for i in range(r, 0, -1):
+            cum += float(abs(s[i - 1]) ** 2)
+            if math.sqrt(cum) > truncerr * nrm:
+                r = i
+                break
+    r = min(r, max_bond)
+    return U[:, :r], s[:r], Vt[:r, :]
+
+
+def svdtrunc_shadowed(A: np.ndarray, max_bond=None, truncerr: float = 0.0):
+    """src/tt_tools.jl:737-741 — dead code for Matrix inputs; kept for documentation."""
+    U, s, Vt = sla.svd(A, full_matrices=False, lapack_driver="gesdd")
+    if max_bond is None:
+        max_bond = max(A.shape)
+    r = min(max_bond, int(np.count_nonzero(s >= truncerr)))
+    return U[:, :r], s[:r], Vt[:r, :]
+
+
+# --------------------------------------------------------------------------------------
+# _tt_bond_truncate! / tt_compress! — src/tt_tools.jl:743-789
+# --------------------------------------------------------------------------------------
+def tt_bond_truncate_(psi: TTvector, k: int, max_bond: int = 2 ** 62, truncerr: float = 0.0,
+                      faithful: bool = False, svals_out: list | None = None):
+    """k is 1-based.  Mutates psi (cores k, k+1 and ttv_rks[k]); ttv_ot is untouched.
+
+    ``faithful=True`` also performs the reference's trailing ``orthogonalize(psi; i=k)``
+    (src/tt_tools.jl:769) and returns it; tt_compress! discards that value.
+    """
+    assert 1 <= k < psi.N, "k must be in 1:(N-1)"
+    Ck, Ck1 = psi.ttv_vec[k - 1], psi.ttv_vec[k]
+    d1, Dl, _ = Ck.shape
+    d2, _, Dr = Ck1.shape
+    # AAC[alpha,s1,s2,beta]; M[(alpha + Dl*s1), (s2 + d2*beta)]
+    M = np.einsum("sag,tgb->sabt", Ck, Ck1).reshape(d1 * Dl, Dr * d2)
+    U, s, Vt = svdtrunc(M, max_bond=max_bond, truncerr=truncerr)
+    if svals_out is not None:
+        svals_out.append(s.copy())
+    ssq = np.sqrt(s)
+    U = U * ssq[None, :]
+    Vt = ssq[:, None] * Vt
+    r = U.shape[1]
+    psi.ttv_vec[k - 1] = U.reshape(d1, Dl, r).copy()
+    psi.ttv_vec[k] = Vt.reshape(r, Dr, d2).transpose(2, 0, 1).copy()
+    psi.ttv_rks[k] = r
+    if faithful:
+        return orthogonalize(psi, i=k)
+    return None
+
+
+def tt_compress_(psi: TTvector, max_bond: int, truncerr: float = 0.0, sweeps: int = 1,
+                 faithful: bool = False, svals_out: list | None = None) -> TTvector:
+    assert sweeps >= 1, "sweeps must be >= 1"
+    for _ in range(sweeps):
+        for k in range(1, psi.N):
+            tt_bond_truncate_(psi, k, max_bond=max_bond, truncerr=truncerr, faithful=faithful, svals_out=svals_out)
+        for k in range(psi.N - 1, 0, -1):
+            tt_bond_truncate_(psi, k, max_bond=max_bond, truncerr=truncerr, faithful=faithful, svals_out=svals_out)
+    return psi

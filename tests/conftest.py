@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are selected with `-m gpu`; if someone runs the whole suite on a box without
+    # a GPU they are skipped (never silently passed through a CPU fallback).
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

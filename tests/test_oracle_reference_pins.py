@@ -1,0 +1,289 @@
+"""Pins the CPU oracle (oracle/tt_oracle.py) to the reference's own known-answer tests.
+
+Each test restates the INPUTS and EXPECTED PROPERTIES of a test in /root/reference/test
+(cited per test); expected values are closed forms or dense linear algebra, so no Julia
+run is needed.  CPU only.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import tt_oracle as O
+
+PI = math.pi
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+# test/test_tt_tools.jl:929-947
+def test_r_and_d_to_rks_reference_vectors():
+    dims = (2, 3, 4)
+    out = O.r_and_d_to_rks([1, 100, 100, 1], dims)
+    assert out[0] == 1 and out[-1] == 1 and out[1] <= 2 and out[2] <= 4
+    assert out == [1, 2, 4, 1]
+    assert O.r_and_d_to_rks([1, 1, 1, 1], dims) == [1, 1, 1, 1]
+    assert O.r_and_d_to_rks([5, 5, 5], (0, 2), rmax=4) == [1, 2, 1]
+    assert O.r_and_d_to_rks([5, 5, 5], (0, 0), rmax=4) == [1, 4, 1]
+
+
+# C3 rank profile of rand_tt(dims, 64) (src/tt_tools.jl:134-139)
+def test_rank_profile_c3():
+    rks = O.r_and_d_to_rks([64] * 31, (2,) * 30, rmax=64)
+    assert rks == [1, 2, 4, 8, 16, 32] + [64] * 19 + [32, 16, 8, 4, 2, 1]
+
+
+# test/test_qtt_tools.jl:111-126 + closed form sin(lam*pi*x) on the reference grid
+@pytest.mark.parametrize("d", [3, 6, 8])
+def test_qtt_sin_closed_form(d):
+    tt = O.qtt_sin(d, lam=PI)
+    assert tt.ttv_vec[0].shape == (2, 1, 2) and tt.ttv_vec[d - 1].shape == (2, 2, 1)
+    assert tt.ttv_vec[0][0, 0, 0] == math.sin(0.0) and tt.ttv_vec[0][0, 0, 1] == math.cos(0.0)
+    x = np.linspace(0, 1, 2 ** d)
+    assert np.allclose(O.qtt_to_vector(tt), np.sin(PI * PI * x), atol=1e-12)
+
+
+# test/test_qtt_multidim.jl:240-242 and test/test_tt_operators.jl (Δ vs tridiagonal)
+@pytest.mark.parametrize("d", [2, 3, 4, 6])
+def test_delta_is_tridiagonal(d):
+    A = O.Delta(d)
+    assert A.tto_rks == [1] + [3] * (d - 1) + [1]
+    n = 2 ** d
+    ref = 2 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)
+    assert np.array_equal(O.qtto_to_matrix(A), ref)
+
+
+def test_toeplitz_general_bands():
+    d = 4
+    n = 2 ** d
+    M = O.qtto_to_matrix(O.toeplitz_to_qtto(0.5, 3.0, -7.0, d))
+    ref = 0.5 * np.eye(n) + 3.0 * np.eye(n, k=1) - 7.0 * np.eye(n, k=-1)  # beta super, gamma sub
+    assert np.array_equal(M, ref)
+
+
+# test/test_tt_operations.jl:41-71 (hadamard closed forms, atol 1e-12)
+def test_hadamard_closed_forms():
+    d = 8
+    x = np.linspace(0, 1, 2 ** d)
+    A1 = O.qtt_exp(d)
+    A2 = O.qtt_sin(d, lam=PI)
+    A3 = O.qtt_cos(d, lam=PI)
+    A4 = O.qtt_polynom([0.0, 2.0, 3.0, -8.0, -5.0], d, a=0.0, b=1.0)
+    poly = 2 * x + 3 * x ** 2 - 8 * x ** 3 - 5 * x ** 4
+    assert np.allclose(O.qtt_to_vector(O.hadamard(A2, A3)), np.cos(PI ** 2 * x) * np.sin(PI ** 2 * x), atol=1e-12, rtol=0)
+    assert np.allclose(O.qtt_to_vector(O.hadamard(A1, A2)), np.exp(x) * np.sin(PI ** 2 * x), atol=1e-12, rtol=0)
+    assert np.allclose(O.qtt_to_vector(O.hadamard(A4, A2)), poly * np.sin(PI ** 2 * x), atol=1e-12, rtol=0)
+    assert np.allclose(O.qtt_to_vector(O.hadamard(A4, A3)), poly * np.cos(PI ** 2 * x), atol=1e-12, rtol=0)
+
+
+# test/test_tt_operations.jl:106-114
+def test_add_inplace_ranks():
+    rng = _rng(1)
+    x = O.rand_tt((2, 3), [1, 2, 1], rng)
+    y = O.rand_tt((2, 3), [1, 3, 1], rng)
+    expected = O.ttv_to_tensor(O.add(x, y))
+    assert np.allclose(expected, O.ttv_to_tensor(x) + O.ttv_to_tensor(y), atol=1e-12)
+    r = O.add_(x, y)
+    assert r is x
+    assert np.allclose(O.ttv_to_tensor(x), expected, atol=1e-12)
+    assert x.ttv_rks == [1, 5, 1] and all(o == 0 for o in x.ttv_ot)
+
+
+# test/test_tt_operations.jl:116-122 + dense check of the contraction
+def test_apply_vs_dense():
+    rng = _rng(2)
+    dims = (2, 3)
+    A = O.rand_tto(dims, 2, rng)
+    v = O.rand_tt(dims, [1, 2, 1], rng)
+    y = O.apply(A, v)
+    assert y.ttv_rks == [a * b for a, b in zip(A.tto_rks, v.ttv_rks)] and all(o == 0 for o in y.ttv_ot)
+    TA = O.tto_to_tensor(A)  # [x1,x2,y1,y2]
+    ref = np.einsum("abcd,cd->ab", TA, O.ttv_to_tensor(v))
+    assert np.allclose(O.ttv_to_tensor(y), ref, atol=1e-12)
+
+
+# test/test_qtt_multidim.jl:658-682 restated in 1-D: Δ action vs dense matvec, < 1e-8
+def test_laplacian_action():
+    d = 6
+    v = O.qtt_sin(d, lam=1.0)
+    Av = O.apply(O.Delta(d), v)
+    ref = O.qtto_to_matrix(O.Delta(d)) @ O.qtt_to_vector(v)
+    assert np.max(np.abs(O.qtt_to_vector(Av) - ref)) < 1e-8
+
+
+# test/test_tt_operations.jl:303-320 and test/test_qtt_multidim.jl:464-473
+def test_dot_norm_vs_dense():
+    d = 8
+    A1 = O.qtt_exp(d)
+    A2 = O.qtt_sin(d, lam=PI)
+    S1, S2 = O.qtt_to_vector(A1), O.qtt_to_vector(A2)
+    assert O.euclidean_distance(A1, A1) == 0.0
+    assert math.isclose(O.dot(A1, A2), float(S1 @ S2), rel_tol=1e-10)
+    assert math.isclose(O.norm(A2), float(np.linalg.norm(S2)), rel_tol=1e-10)
+    assert abs(math.sqrt(S1 @ S1 - 2 * (S1 @ S2) + S2 @ S2) - O.euclidean_distance(A1, A2)) < 1e-10
+
+
+# test/test_tt_tools.jl:981-1017
+def test_orthogonalize_properties():
+    rng = _rng(3)
+    dims = (2, 3, 4)
+    tt = O.rand_tt(dims, [1, 2, 3, 1], rng)
+    T0 = O.ttv_to_tensor(tt)
+    for center in (1, 2, 3):
+        orth = O.orthogonalize(tt, i=center)
+        assert np.allclose(O.ttv_to_tensor(orth), T0, atol=1e-12)
+        assert orth.ttv_ot[center - 1] == 0
+        assert all(orth.ttv_ot[j] == 1 for j in range(center - 1))
+        assert all(orth.ttv_ot[j] == -1 for j in range(center, 3))
+        for j in range(center - 1):
+            G = orth.ttv_vec[j]
+            n, rl, rr = G.shape
+            A = G.transpose(1, 0, 2).reshape(rl * n, rr, order="F")  # reshape(permutedims(G,(2,1,3)), rl*n, rr)
+            assert np.allclose(A.T @ A, np.eye(rr), atol=1e-12)
+        for j in range(center, 3):
+            G = orth.ttv_vec[j]
+            n, rl, rr = G.shape
+            A = G.transpose(1, 2, 0).reshape(rl, rr * n, order="F")
+            assert np.allclose(A @ A.T, np.eye(rl), atol=1e-12)
+
+
+# test/test_tdvp.jl:28-44
+def test_svdtrunc_truncerr_zero():
+    rng = _rng(4)
+    A = rng.standard_normal((6, 4))
+    U, S, Vt = O.svdtrunc(A, max_bond=100, truncerr=0.0)
+    assert U.shape[0] == 6 and Vt.shape[1] == 4 and len(S) == U.shape[1] == Vt.shape[0] == 4
+    U2, S2, Vt2 = O.svdtrunc(A, max_bond=2, truncerr=0.0)
+    assert len(S2) == 2
+    assert np.allclose(S2, np.linalg.svd(A, compute_uv=False)[:2], rtol=1e-12, atol=1e-12)
+    assert len(O.svdtrunc(rng.standard_normal((5, 5)), max_bond=1)[1]) == 1
+
+
+def test_svdtrunc_relative_tail_rule():
+    # src/tt_cross_interpolation.jl:153-163: drop the longest tail with 2-norm <= truncerr*||s||
+    s = np.array([1.0, 1e-3, 1e-7, 1e-9])
+    A = np.diag(s)
+    assert len(O.svdtrunc(A, truncerr=1e-6)[1]) == 2
+    assert len(O.svdtrunc(A, truncerr=1e-8)[1]) == 3
+    assert len(O.svdtrunc(A, truncerr=0.0)[1]) == 4
+    # all-zero matrix: loop never breaks, r stays len(s)
+    assert len(O.svdtrunc(np.zeros((3, 3)), truncerr=1e-3)[1]) == 3
+
+
+# test/test_tt_tools.jl:433-498
+def test_bond_truncate_shapes_rank1_and_assert():
+    rng = _rng(5)
+    tt = O.TTvector(3, [rng.standard_normal((2, 1, 4)), rng.standard_normal((2, 4, 4)), rng.standard_normal((2, 4, 1))],
+                    (2, 2, 2), [1, 4, 4, 1], [0, 0, 0])
+    y = O.tt_bond_truncate_(tt, 1, max_bond=2, truncerr=0.0, faithful=True)
+    assert tt.ttv_rks[1] <= 2
+    r = tt.ttv_rks[1]
+    assert tt.ttv_vec[0].shape == (2, 1, r) and tt.ttv_vec[1].shape == (2, r, 4)
+    assert y.ttv_rks[1] == tt.ttv_rks[1] and y.ttv_vec[0].shape == tt.ttv_vec[0].shape
+
+    u, v, p, q = [1.2, -0.5], [0.7, 0.3], [2.0, 3.0], [4.0, 5.0]
+    c1 = np.zeros((2, 1, 2))
+    c2 = np.zeros((2, 2, 1))
+    for s in range(2):
+        for g in range(2):
+            c1[s, 0, g] = p[g] * u[s]
+            c2[s, g, 0] = q[g] * v[s]
+    tt2 = O.TTvector(2, [c1, c2], (2, 2), [1, 2, 1], [0, 0])
+    T0 = O.ttv_to_tensor(tt2)
+    O.tt_bond_truncate_(tt2, 1, max_bond=1)
+    assert tt2.ttv_rks[1] == 1 and tt2.ttv_vec[0].shape == (2, 1, 1) and tt2.ttv_vec[1].shape == (2, 1, 1)
+    assert np.allclose(O.ttv_to_tensor(tt2), T0, atol=1e-12)
+
+    tt3 = O.rand_tt((2, 2, 2), [1, 2, 2, 1], rng)
+    with pytest.raises(AssertionError):
+        O.tt_bond_truncate_(tt3, 0)
+    with pytest.raises(AssertionError):
+        O.tt_bond_truncate_(tt3, tt3.N)
+
+
+# test/test_tt_tools.jl:500-574
+def test_tt_compress_behaviour():
+    rng = _rng(6)
+    tt = O.rand_tt((2, 2, 2), [1, 2, 2, 1], rng)
+    before = list(tt.ttv_rks)
+    T0 = O.ttv_to_tensor(tt)
+    y = O.tt_compress_(tt, 10, sweeps=1)
+    assert y is tt and tt.ttv_rks == before
+    assert np.allclose(O.ttv_to_tensor(tt), T0, atol=1e-12)
+
+    tt = O.rand_tt((2, 2, 2, 2), [1, 4, 4, 4, 1], rng)
+    y = O.tt_compress_(tt, 2, sweeps=1)
+    assert y is tt and max(tt.ttv_rks) <= 2
+    for i in range(4):
+        assert tt.ttv_vec[i].shape == (2, tt.ttv_rks[i], tt.ttv_rks[i + 1])
+    with pytest.raises(AssertionError):
+        O.tt_compress_(O.rand_tt((2, 2, 2), [1, 2, 2, 1], rng), 2, sweeps=0)
+    tt = O.rand_tt((2, 2, 2), [1, 3, 3, 1], rng)
+    assert O.tt_compress_(tt, 3, sweeps=2, truncerr=0.0) is tt
+
+
+# test/test_qtt_multidim.jl:577-597 restated with closed-form inputs: a separable exponential
+# (rank-1 in QTT) padded to rank 4 compresses back to rank 1 with values < 1e-10.
+def test_compress_separable_exp_to_rank1():
+    d = 12
+    e = O.qtt_exp(d, alpha=-1.0)
+    padded = O.add(O.add(e, O.scale(0.5, e)), O.add(O.scale(-0.25, e), e))  # rank 4, same function * 2.25
+    assert max(padded.ttv_rks) == 4
+    O.tt_compress_(padded, 10, truncerr=1e-12)
+    assert max(padded.ttv_rks) == 1
+    x = np.linspace(0, 1, 2 ** d)
+    assert np.max(np.abs(O.qtt_to_vector(padded) - 2.25 * np.exp(-x))) < 1e-10
+
+
+# test/test_qtt_multidim.jl:599-614 restated: sin*sin, max_bond 8, truncerr 1e-12 -> < 1e-8
+def test_compress_sinsin_accuracy():
+    d = 10
+    s = O.qtt_sin(d, lam=2.0)
+    h = O.hadamard(s, O.qtt_cos(d, lam=3.0))           # rank 4, exactly representable with rank <= 4
+    big = O.add(h, O.scale(1e-3, O.hadamard(s, s)))       # rank 8
+    ref = O.qtt_to_vector(big)
+    O.tt_compress_(big, 8, truncerr=1e-12)
+    assert max(big.ttv_rks) <= 8
+    assert np.max(np.abs(O.qtt_to_vector(big) - ref)) < 1e-8
+
+
+# BASELINE.json config 1 + README.md:84-103 inputs: tt_compress!(id_tto(6)*qtt_sin(6, λ=π), 2)
+def test_config1_plumbing():
+    A, x = O.id_tto(6), O.qtt_sin(6, lam=PI)
+    y = O.apply(A, x)
+    assert y.ttv_rks == [1, 2, 2, 2, 2, 2, 1]
+    O.tt_compress_(y, 2)
+    assert y.ttv_rks == [1, 2, 2, 2, 2, 2, 1]
+    grid = np.linspace(0, 1, 64)
+    assert np.allclose(O.qtt_to_vector(y), np.sin(PI * PI * grid), atol=1e-12)
+
+
+# test/test_euler.jl:269-298: one RK4 step built from apply + '+' + scalar* + tt_compress!
+def test_rk4_step_vs_dense():
+    rng = _rng(7)
+    d = 4
+    hh = 1 / d ** 2
+    A = O.toeplitz_to_qtto(-2.0, 1.0, 1.0, d)
+    A = O.TToperator(A.N, [c.copy() for c in A.tto_vec], A.tto_dims, A.tto_rks, A.tto_ot)
+    A.tto_vec[0] = (-hh ** 2) * A.tto_vec[0]   # scalar * TToperator scales the first core with ot == 0
+    u0 = O.rand_tt((2,) * d, [1, 2, 2, 2, 1], rng)
+    h, mb = 0.05, 8
+
+    def cmp(t):
+        return O.tt_compress_(t, mb)
+    k1 = O.apply(A, u0)
+    k2 = O.apply(A, cmp(O.add(u0, O.scale(h / 2, k1))))
+    k3 = O.apply(A, cmp(O.add(u0, O.scale(h / 2, k2))))
+    k4 = O.apply(A, cmp(O.add(u0, O.scale(h, k3))))
+    incr = O.scale(h / 6, cmp(O.add(O.add(O.add(k1, O.scale(2, k2)), O.scale(2, k3)), k4)))
+    sol = cmp(O.add(u0, incr))
+
+    Ad, ud = O.qtto_to_matrix(A), O.qtt_to_vector(u0)
+    K1 = Ad @ ud
+    K2 = Ad @ (ud + h / 2 * K1)
+    K3 = Ad @ (ud + h / 2 * K2)
+    K4 = Ad @ (ud + h * K3)
+    ref = ud + h / 6 * (K1 + 2 * K2 + 2 * K3 + K4)
+    assert np.linalg.norm(O.qtt_to_vector(sol) - ref) / np.linalg.norm(ref) < 1e-6
