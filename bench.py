@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — "QTT Laplacian apply + round" throughput in TT cores per second on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--d 30] [--rank 64]
+
+One STEP = one pass of the hot path over one batch of B independent synthetic trains resident in HBM:
+    y_b = tt_compress!(Δ(d) * x_b, rank)       for b = 1..B      (src/solvers/euler.jl:55's operator)
+i.e. ttn_apply (HBM-bound streaming kernel) + ttn_compress (one persistent workgroup per train, fp64
+dense linear algebra: merge GEMM -> Householder LQ -> one-sided Jacobi SVD -> truncate -> split).
+value = (#ranks * B * d) / (max-over-ranks wall time per step)   [TT cores / s], inputs already in HBM.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): trains are independent, so they are
+sharded across ranks with no data-path collective (weak scaling: B trains per GPU); torch.distributed
+(RCCL) is only used for the barriers and the max-over-ranks reduction of the timing.
+
+The JSON line also carries
+  roofline     for the dominant kernel (k_compress): algorithmic fp64 flops of the sweep (SURVEY §8d:
+               merge GEMMs + Golub–Van-Loan thin-SVD count, evaluated on the actual rank profile) x B
+               per launch / average launch duration measured with HIP events on the library's stream;
+  cpu_baseline the CPU oracle ("port": NumPy + LAPACK gesdd, the reference algorithm WITHOUT the
+               discarded per-bond orthogonalize) timed on this box's host cores, one train per core;
+  single_train the same step with B = 1 (latency of one train; one workgroup = one CU is busy).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6     # AMD MI355X public fp64 vector = matrix peak; MI355X_MICROARCH.md has no fp64 row
+
+
+def sweep_algorithmic_flops(d, rks_in, rks_out_after_lr, max_bond, n=2):
+    """Algorithmic fp64 flops of one tt_compress! (sweeps=1, truncerr=0) on input ranks `rks_in`:
+    per bond step 2*mr*mc*rm (merge GEMM, src/tt_tools.jl:749) + thin-SVD Golub–Van-Loan count
+    6*M*N^2 + 20*N^3 with M >= N."""
+    def svd_flops(a, b):
+        M, N = max(a, b), min(a, b)
+        return 6.0 * M * N * N + 20.0 * N ** 3
+    total = 0.0
+    r = list(rks_in)
+    for k in range(d - 1):                       # L -> R
+        mr, mc, rm = n * r[k], n * r[k + 2], r[k + 1]
+        total += 2.0 * mr * mc * rm + svd_flops(mr, mc)
+        r[k + 1] = min(mr, mc, max_bond)
+    for k in range(d - 2, -1, -1):               # R -> L
+        mr, mc, rm = n * r[k], n * r[k + 2], r[k + 1]
+        total += 2.0 * mr * mc * rm + svd_flops(mr, mc)
+        r[k + 1] = min(mr, mc, max_bond)
+    return total
+
+
+def _cpu_worker(args):
+    d, rank, seed, reps, faithful = args
+    from threadpoolctl import threadpool_limits
+    import ttn_amd as T
+    from oracle import tt_oracle as O
+    from tests.helpers import to_oracle
+    with threadpool_limits(limits=1):
+        x = to_oracle(T.rand_tt((2,) * d, rank, seed=seed))
+        A = O.Delta(d)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            O.tt_compress_(O.apply(A, x), rank, faithful=faithful)
+        return time.perf_counter() - t0
+
+
+def cpu_baseline(d, rank, budget_s=20.0):
+    """Oracle (reference algorithm, lean: without the discarded orthogonalize) on the host cores,
+    one independent train per process, BLAS pinned to 1 thread per process."""
+    import multiprocessing as mp
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    t1 = _cpu_worker((d, rank, 30, 1, False))                     # calibrate on one train
+    reps = max(1, min(8, int(budget_s / max(t1, 1e-3))))
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker, [(d, rank, 30 + c, reps, False) for c in range(cores)])
+        wall = time.perf_counter() - t0
+    # includes process start-up; subtract nothing (conservative for the GPU/CPU ratio is to favour the CPU,
+    # so also report the single-core figure measured without any pool overhead)
+    multi = cores * reps * d / wall
+    single = d / t1
+    value = max(multi, single * 1.0)
+    out = {"value": round(value, 2), "unit": "TT cores/s", "cores": cores if multi >= single else 1, "kind": "port",
+           "sample": f"{cores} procs x {reps} trains of d={d} rank={rank} (lean oracle, NumPy+LAPACK gesdd, 1 BLAS thread/proc); "
+                     f"single-core {single:.1f} cores/s"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="independent trains per GPU per step")
+    ap.add_argument("--d", type=int, default=30)
+    ap.add_argument("--rank", type=int, default=64)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import ttn_amd as T
+    from ttn_amd import device as D
+    T.ensure_init(local_rank)
+
+    d, r, B = args.d, args.rank, args.batch
+    A = T.Delta(d)
+    dA = T.DeviceTTO(A)
+    x0 = T.rand_tt((2,) * d, r, seed=30)
+    dx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=B)
+    for b in range(B):                                        # distinct synthetic trains, seeds 30 + global index
+        dx.upload(b, T.rand_tt((2,) * d, r, seed=30 + rank * B + b))
+    ycap = [a * c for a, c in zip(A.tto_rks, x0.ttv_rks)]
+    dy = T.DeviceTT((2,) * d, ycap, batch=B)
+
+    def barrier():
+        D.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def step(i=None):
+        D.apply(dA, dx, dy)
+        if i is not None:
+            D.event_record(2 * i)
+        D.tt_compress_(dy, r)
+        if i is not None:
+            D.event_record(2 * i + 1)
+
+    for _ in range(args.warmup):
+        step()
+    D.compress_status(dy)                                      # raises if any Jacobi SVD failed to converge
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    D.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.barrier()
+    sweeps = D.compress_status(dy)
+    kms = [D.event_elapsed_ms(2 * i, 2 * i + 1) for i in range(args.steps)]
+    k_avg_s = sum(kms) / len(kms) / 1e3
+    out_rks, _ = dy.ranks(0)
+
+    single = None
+    if rank == 0 and not args.no_single:
+        sx = T.DeviceTT.from_host(x0)
+        sy = T.DeviceTT((2,) * d, ycap)
+        for _ in range(2):
+            D.apply(dA, sx, sy); D.tt_compress_(sy, r)
+        D.sync()
+        ts = time.perf_counter()
+        nrep = 5
+        for _ in range(nrep):
+            D.apply(dA, sx, sy); D.tt_compress_(sy, r)
+        D.sync()
+        tsingle = (time.perf_counter() - ts) / nrep
+        single = {"value": round(d / tsingle, 1), "unit": "TT cores/s", "ms_per_step": round(tsingle * 1e3, 3), "batch": 1}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * d / (elapsed / args.steps)
+        flops = sweep_algorithmic_flops(d, ycap, None, r) * B
+        achieved = flops / k_avg_s / 1e12
+        res = {
+            "metric": "TT cores/sec for QTT Laplacian apply+round, d=%d rank-%d" % (d, r),
+            "value": round(value, 1), "unit": "TT cores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3: tt_compress!(Delta(%d)*x, %d), x = rand_tt(dims=2^%d, rank %d), batch of %d independent "
+                                   "trains per GPU resident in HBM (seeds 30+i), truncerr=0, sweeps=1" % (d, r, d, r, B),
+                       "d": d, "rank": r, "batch_per_gpu": B, "parallelism": "trains sharded over %d GPU(s), no collective" % world,
+                       "out_ranks": out_rks},
+            "roofline": {"bound": "mfma", "kernel": "k_compress", "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                         "algorithmic_flops_per_launch": flops, "avg_launch_ms": round(k_avg_s * 1e3, 3),
+                         "jacobi_sweeps_per_train": sweeps[0]},
+        }
+        if single is not None:
+            res["single_train"] = single
+        if not args.no_cpu and world == 1:
+            res["cpu_baseline"] = cpu_baseline(d, r)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

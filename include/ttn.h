@@ -1,0 +1,169 @@
+/*
+ * ttn.h — C ABI of the MI355X-native TT/QTT core-arithmetic backend ("libttn_hip.so").
+ *
+ * This is the drop-in boundary for ONE hot path of TensorTrainNumerics.jl v1.1.3: TT-operator
+ * apply, TT dot / hadamard / + / scalar*, orthogonalize and the tt_compress! rounding sweep.  The
+ * reference has no FFI of its own (it is pure Julia; L1 is reached by multiple dispatch), so every
+ * entry point below cites the Julia method it replaces; the Julia-side `ccall` binding a maintainer
+ * would add is shown in INTEGRATION.md and julia/TTNBackend.jl.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all integers are int64_t, all payload is double (fp64);
+ *   - arrays are COLUMN-MAJOR exactly as the reference stores them:
+ *       vector core  k : (n_k, r_{k-1}, r_k)            offset i + n*(a + r_{k-1}*b)
+ *       operator core k: (n_k, n_k, R_{k-1}, R_k)       offset i + n*(j + n*(a + R_{k-1}*b))
+ *     (src/tt_tools.jl:23-29, :48-54); rank vectors have length d+1, `ot` vectors length d;
+ *   - site numbers (`k`, `center`) are 1-based like the reference;
+ *   - every function returns int: 0 = ok, <0 = argument error (the Julia shim maps these to the
+ *     AssertionError the reference throws), >0 = HIP runtime error (hipError_t value).
+ *     Functions never throw and never abort.  ttn_last_error_string() describes the last failure.
+ *   - the library is usable from any host thread; calls are serialised internally on one HIP stream.
+ */
+#ifndef TTN_H
+#define TTN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (negative = argument errors, mirrored as AssertionError on the host side) ---- */
+#define TTN_OK                 0
+#define TTN_ERR_DIMS          -1   /* "Incompatible dimensions"  (tt_operations.jl:11,102,240,344) */
+#define TTN_ERR_BOND_INDEX    -2   /* "k must be in 1:(N-1)"     (tt_tools.jl:744)                  */
+#define TTN_ERR_SWEEPS        -3   /* "sweeps must be >= 1"      (tt_tools.jl:773)                  */
+#define TTN_ERR_CENTER        -4   /* "Impossible orthogonalization" (tt_tools.jl:513)              */
+#define TTN_ERR_CAPACITY      -5   /* destination handle too small for the result ranks             */
+#define TTN_ERR_ARG           -6   /* null pointer / non-positive size / bad handle                 */
+#define TTN_ERR_NOT_INIT      -7   /* ttn_init was not called (or failed)                           */
+#define TTN_ERR_UNSUPPORTED   -8   /* shape outside what the kernels support (stated in DESIGN.md)  */
+#define TTN_ERR_NO_CONVERGENCE -9  /* Jacobi SVD hit its sweep limit on some bond                   */
+
+/* ---- library lifetime ------------------------------------------------------------------------ */
+int         ttn_init(int device);            /* binds to HIP device `device`, creates the stream   */
+int         ttn_finalize(void);
+const char* ttn_version(void);
+const char* ttn_last_error_string(void);
+int         ttn_sync(void);                  /* hipStreamSynchronize on the library stream          */
+int         ttn_device_count(int* n);        /* hipGetDeviceCount (does not initialise a device)    */
+
+/* ---- device-resident handles ------------------------------------------------------------------
+ * A ttn_tt is a BATCH of `batch` TT vectors with common d/dims and a common per-bond rank CAPACITY;
+ * each train carries its own current ranks (they live on the device because tt_compress! makes them
+ * data dependent).  One contiguous fp64 arena: train b, core k at  data + b*stride + off[k].
+ * A ttn_tto is one TT operator shared by every train of a batch.
+ * Replaces: TTvector / TToperator containers (src/tt_tools.jl:23-29, :48-54).
+ */
+typedef struct ttn_tt_s*  ttn_tt_t;
+typedef struct ttn_tto_s* ttn_tto_t;
+
+int ttn_tt_create(int64_t d, const int64_t* dims, const int64_t* cap_rks, int64_t batch, ttn_tt_t* out);
+int ttn_tt_free(ttn_tt_t h);
+/* cores[k] points at n_k*rks[k]*rks[k+1] doubles (host memory, column-major) */
+int ttn_tt_upload(ttn_tt_t h, int64_t b, const double* const* cores, const int64_t* rks, const int64_t* ot);
+/* copies train `src_b` (cores + ranks + ot) over every other train of the batch, on the device */
+int ttn_tt_replicate(ttn_tt_t h, int64_t src_b);
+/* current ranks / ot flags of train b (synchronises the stream) */
+int ttn_tt_ranks(ttn_tt_t h, int64_t b, int64_t* rks, int64_t* ot);
+/* cores[k] must have room for n_k*rks[k]*rks[k+1] doubles with the CURRENT ranks (see ttn_tt_ranks) */
+int ttn_tt_download(ttn_tt_t h, int64_t b, double* const* cores);
+int ttn_tt_batch(ttn_tt_t h, int64_t* batch);
+/* device copy dst <- src (same d/dims, dst capacity >= src current ranks) */
+int ttn_tt_copy(ttn_tt_t dst, ttn_tt_t src);
+
+int ttn_tto_create(int64_t d, const int64_t* dims, const int64_t* rks, const double* const* cores, ttn_tto_t* out);
+int ttn_tto_free(ttn_tto_t h);
+
+/* ---- the hot path on handles (every op runs on all trains of the batch, asynchronously) -------- */
+
+/* y = A * x       replaces *(A::TToperator, v::TTvector), src/tt_operations.jl:101-111 */
+int ttn_apply(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y);
+
+/* tt_compress!(psi, max_bond; truncerr, sweeps)   src/tt_tools.jl:772-789 (+ :743-768 per bond and the
+ * effective _svdtrunc, src/tt_cross_interpolation.jl:149-166).  The reference's trailing
+ * `orthogonalize(psi; i=k)` (:769) is not computed: tt_compress! discards its value (:779,:785). */
+int ttn_compress(ttn_tt_t psi, int64_t max_bond, double truncerr, int64_t sweeps);
+
+/* status of the last ttn_compress / ttn_bond_truncate on this batch (synchronises): returns
+ * TTN_ERR_NO_CONVERGENCE if the Jacobi SVD of any bond hit its sweep limit; if non-null,
+ * total_jacobi_sweeps[b] receives the number of Jacobi sweeps train b used (diagnostics). */
+int ttn_compress_status(ttn_tt_t psi, int64_t* total_jacobi_sweeps);
+
+/* _tt_bond_truncate!(psi, k; max_bond, truncerr) without the discarded orthogonalize; k is 1-based */
+int ttn_bond_truncate(ttn_tt_t psi, int64_t k, int64_t max_bond, double truncerr);
+
+/* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
+int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);
+
+/* out[b] = dot(a_b, b_b)      src/tt_operations.jl:239-250 ; out is HOST memory, length batch (synchronises) */
+int ttn_dot(ttn_tt_t a, ttn_tt_t b, double* out);
+/* out[b] = norm(a_b) = sqrt(max(dot(a,a),0))   src/tt_operations.jl:465-470 */
+int ttn_norm(ttn_tt_t a, double* out);
+
+/* z = hadamard(x, y)   src/tt_operations.jl:343-361 */
+int ttn_hadamard(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z);
+/* z = x + y            src/tt_operations.jl:10-35 (also the body of add!, :37-66) */
+int ttn_add(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z);
+/* y = a * x            src/tt_operations.jl:256-266 (scales the first core with ot==0, else core 1;
+ *                      a == 0 gives the all-zero train with ot reset to 0) */
+int ttn_scale(double a, ttn_tt_t x, ttn_tt_t y);
+/* y = orthogonalize(x; i=center)   src/tt_tools.jl:511-543 ; center is 1-based */
+int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y);
+
+/* ---- parity instrumentation: singular values seen by the last ttn_compress / ttn_bond_truncate --
+ * After ttn_sv_capture(h, 1), each bond step stores ALL singular values of its merged matrix (sorted,
+ * descending, before truncation).  `step` counts bond steps of the last call from 0
+ * (L->R k=1..N-1, then R->L k=N-1..1, per sweep).  Returns the count in *n (<= cap). */
+int ttn_sv_capture(ttn_tt_t h, int enable);
+int ttn_sv_get(ttn_tt_t h, int64_t b, int64_t step, double* out, int64_t cap, int64_t* n);
+
+/* ---- timing on the library stream (HIP events) ------------------------------------------------- */
+int ttn_timer_begin(void);
+int ttn_timer_end(float* ms);   /* synchronises */
+/* event slots (0..4095) recorded on the library stream without synchronising; elapsed() synchronises */
+int ttn_event_record(int64_t slot);
+int ttn_event_elapsed(int64_t slot_a, int64_t slot_b, float* ms);
+
+/* ---- stateless host-pointer entry points: the literal drop-ins for one train --------------------
+ * Each uploads, runs the handle op above, and downloads.  Output cores are caller-allocated:
+ *   apply     : Y_cores[k] sized n_k*(A_rks[k]*X_rks[k])*(A_rks[k+1]*X_rks[k+1])   (as zeros_tt would)
+ *   hadamard  : Z_cores[k] sized n_k*(rx*ry)_k*(rx*ry)_{k+1}
+ *   add       : Z_cores[k] sized with ranks rx+ry (ends forced to 1)
+ *   compress  : in/out cores sized for the INPUT ranks; `rks` is updated in place; cores are rewritten
+ *               compactly with the new ranks (the Julia shim re-wraps them to exact-size Arrays)
+ *   orthogonalize: Y_cores sized for r_and_d_to_rks(X_rks) ; Y_rks / Y_ot are outputs
+ */
+int ttn_apply_f64(int64_t d, const int64_t* dims,
+                  const double* const* A_cores, const int64_t* A_rks,
+                  const double* const* X_cores, const int64_t* X_rks,
+                  double* const* Y_cores);
+int ttn_dot_f64(int64_t d, const int64_t* dims,
+                const double* const* A_cores, const int64_t* A_rks,
+                const double* const* B_cores, const int64_t* B_rks, double* out);
+int ttn_hadamard_f64(int64_t d, const int64_t* dims,
+                     const double* const* X_cores, const int64_t* X_rks,
+                     const double* const* Y_cores, const int64_t* Y_rks,
+                     double* const* Z_cores);
+int ttn_add_f64(int64_t d, const int64_t* dims,
+                const double* const* X_cores, const int64_t* X_rks,
+                const double* const* Y_cores, const int64_t* Y_rks,
+                double* const* Z_cores);
+int ttn_scale_f64(int64_t d, const int64_t* dims, double a,
+                  const double* const* X_cores, const int64_t* X_rks, const int64_t* X_ot,
+                  double* const* Y_cores, int64_t* Y_ot);
+int ttn_orthogonalize_f64(int64_t d, const int64_t* dims,
+                          const double* const* X_cores, const int64_t* X_rks, int64_t center,
+                          double* const* Y_cores, int64_t* Y_rks, int64_t* Y_ot);
+int ttn_compress_f64(int64_t d, const int64_t* dims, double* const* cores, int64_t* rks,
+                     int64_t max_bond, double truncerr, int64_t sweeps);
+int ttn_bond_truncate_f64(int64_t d, const int64_t* dims, double* const* cores, int64_t* rks,
+                          int64_t k, int64_t max_bond, double truncerr);
+
+/* r_and_d_to_rks(rks, dims; rmax)   src/tt_tools.jl:407-425 (host-side integer helper, bit-exact) */
+int ttn_r_and_d_to_rks(int64_t d, const int64_t* dims, int64_t n_rks, const int64_t* rks, int64_t rmax, int64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTN_H */

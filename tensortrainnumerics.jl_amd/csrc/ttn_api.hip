@@ -1,0 +1,858 @@
+// ttn_api.hip — the C ABI of include/ttn.h on top of the HIP kernels (gfx950).
+#include "../../include/ttn.h"
+#include "ttn_common.h"
+#include "ttn_stream_kernels.h"
+#include "ttn_dense_kernels.h"
+#include "ttn_ortho_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// global state
+// ------------------------------------------------------------------------------------------------
+namespace {
+std::recursive_mutex g_mu;
+bool g_init = false;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+std::string g_err = "";
+void* g_scratch = nullptr;
+size_t g_scratch_bytes = 0;
+int* g_status = nullptr;      // per-train status + sweep stats (2 * g_status_cap ints)
+int g_status_cap = 0;
+double* g_dout = nullptr;     // per-train double outputs (dot)
+std::vector<hipEvent_t> g_slots;   // ttn_event_record slots
+int g_dout_cap = 0;
+
+int fail(int code, const char* what) {
+    g_err = what;
+    return code;
+}
+int hipfail(hipError_t e, const char* where) {
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return (int)e > 0 ? (int)e : 999;
+}
+#define HIPCHK(call)                                  \
+    do {                                              \
+        hipError_t e_ = (call);                       \
+        if (e_ != hipSuccess) return hipfail(e_, #call); \
+    } while (0)
+#define NEED_INIT() \
+    if (!g_init) return fail(TTN_ERR_NOT_INIT, "ttn_init has not been called")
+
+int ensure_scratch(size_t bytes) {
+    if (bytes <= g_scratch_bytes) return TTN_OK;
+    if (g_scratch) {
+        HIPCHK(hipStreamSynchronize(g_stream));
+        HIPCHK(hipFree(g_scratch));
+        g_scratch = nullptr;
+        g_scratch_bytes = 0;
+    }
+    HIPCHK(hipMalloc(&g_scratch, bytes));
+    g_scratch_bytes = bytes;
+    return TTN_OK;
+}
+int ensure_batch_bufs(int batch) {
+    if (batch > g_status_cap) {
+        if (g_status) { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipFree(g_status)); }
+        HIPCHK(hipMalloc((void**)&g_status, sizeof(int) * 2 * batch));
+        g_status_cap = batch;
+    }
+    if (batch > g_dout_cap) {
+        if (g_dout) { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipFree(g_dout)); }
+        HIPCHK(hipMalloc((void**)&g_dout, sizeof(double) * batch));
+        g_dout_cap = batch;
+    }
+    return TTN_OK;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct ttn_tt_s {
+    int d = 0, batch = 0;
+    std::vector<int64_t> dims, cap, bound;   // bound[m]: host upper bound on the current rank of any train
+    std::vector<long long> off;               // d+1 slot offsets
+    long long stride = 0;
+    double* d_data = nullptr;
+    long long* d_off = nullptr;
+    long long* d_rks = nullptr;
+    long long* d_cap = nullptr;
+    int* d_dims = nullptr;
+    std::vector<int64_t> ot;                  // [batch][d] host-side gauge flags (never data dependent)
+    // singular-value capture
+    bool sv_on = false;
+    double* d_sv = nullptr;
+    int sv_steps = 0, sv_pmax = 0;
+    TTDev dev() const {
+        TTDev t;
+        t.data = d_data; t.stride = stride; t.off = d_off; t.rks = d_rks; t.dims = d_dims; t.cap = d_cap;
+        t.d = d; t.batch = batch;
+        return t;
+    }
+};
+struct ttn_tto_s {
+    int d = 0;
+    std::vector<int64_t> dims, rks;
+    std::vector<long long> off;
+    double* d_data = nullptr;
+    long long* d_off = nullptr;
+    long long* d_rks = nullptr;
+    int* d_dims = nullptr;
+    TTODev dev() const {
+        TTODev t;
+        t.data = d_data; t.off = d_off; t.rks = d_rks; t.dims = d_dims; t.d = d;
+        return t;
+    }
+};
+
+static bool same_dims(const std::vector<int64_t>& a, const std::vector<int64_t>& b) { return a == b; }
+
+extern "C" {
+
+const char* ttn_version(void) { return "ttn-mi355x 0.1.0 (gfx950, fp64)"; }
+const char* ttn_last_error_string(void) { return g_err.c_str(); }
+
+int ttn_device_count(int* n) {
+    if (!n) return fail(TTN_ERR_ARG, "null pointer");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return hipfail(e, "hipGetDeviceCount"); }
+    *n = c;
+    return TTN_OK;
+}
+
+int ttn_init(int device) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (g_init && device == g_device) return TTN_OK;
+    if (g_init) return fail(TTN_ERR_ARG, "ttn_init: already bound to another device (call ttn_finalize first)");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&g_ev0));
+    HIPCHK(hipEventCreate(&g_ev1));
+    // the compress / orthogonalize kernels use more than the default 64 KiB of dynamic LDS
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compress), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(COMPRESS_LDS_BYTES)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_orthogonalize), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(ORTHO_LDS_BYTES)));
+    g_device = device;
+    g_init = true;
+    return TTN_OK;
+}
+
+int ttn_finalize(void) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!g_init) return TTN_OK;
+    hipStreamSynchronize(g_stream);
+    if (g_scratch) hipFree(g_scratch);
+    if (g_status) hipFree(g_status);
+    if (g_dout) hipFree(g_dout);
+    g_scratch = nullptr; g_scratch_bytes = 0; g_status = nullptr; g_status_cap = 0; g_dout = nullptr; g_dout_cap = 0;
+    hipEventDestroy(g_ev0); hipEventDestroy(g_ev1);
+    for (auto e : g_slots) if (e) hipEventDestroy(e);
+    g_slots.clear();
+    hipStreamDestroy(g_stream);
+    g_stream = nullptr; g_init = false; g_device = -1;
+    return TTN_OK;
+}
+
+int ttn_sync(void) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return TTN_OK;
+}
+
+int ttn_timer_begin(void) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    HIPCHK(hipEventRecord(g_ev0, g_stream));
+    return TTN_OK;
+}
+int ttn_timer_end(float* ms) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!ms) return fail(TTN_ERR_ARG, "null pointer");
+    HIPCHK(hipEventRecord(g_ev1, g_stream));
+    HIPCHK(hipEventSynchronize(g_ev1));
+    HIPCHK(hipEventElapsedTime(ms, g_ev0, g_ev1));
+    return TTN_OK;
+}
+
+int ttn_event_record(int64_t slot) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (slot < 0 || slot >= 4096) return fail(TTN_ERR_ARG, "event slot out of range");
+    if ((int64_t)g_slots.size() <= slot) g_slots.resize(slot + 1, nullptr);
+    if (!g_slots[slot]) HIPCHK(hipEventCreate(&g_slots[slot]));
+    HIPCHK(hipEventRecord(g_slots[slot], g_stream));
+    return TTN_OK;
+}
+int ttn_event_elapsed(int64_t a, int64_t b, float* ms) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!ms || a < 0 || b < 0 || a >= (int64_t)g_slots.size() || b >= (int64_t)g_slots.size() || !g_slots[a] || !g_slots[b])
+        return fail(TTN_ERR_ARG, "event slot not recorded");
+    HIPCHK(hipEventSynchronize(g_slots[b]));
+    HIPCHK(hipEventElapsedTime(ms, g_slots[a], g_slots[b]));
+    return TTN_OK;
+}
+
+// r_and_d_to_rks with Julia's wrapping Int64 products (src/tt_tools.jl:407-425)
+static int64_t wrap_prod(const int64_t* v, int64_t lo, int64_t hi) {  // product of v[lo..hi)
+    uint64_t p = 1;
+    for (int64_t i = lo; i < hi; ++i) p *= (uint64_t)v[i];
+    return (int64_t)p;
+}
+int ttn_r_and_d_to_rks(int64_t d, const int64_t* dims, int64_t n_rks, const int64_t* rks, int64_t rmax, int64_t* out) {
+    if (!dims || !rks || !out || d < 0 || n_rks < 0) return fail(TTN_ERR_ARG, "bad argument");
+    for (int64_t i = 0; i < n_rks; ++i) out[i] = 1;
+    for (int64_t i = 0; i < d && i < n_rks; ++i) {
+        const int64_t q = wrap_prod(dims, i, d), p = wrap_prod(dims, 0, i);
+        int64_t v = rks[i];
+        if (q > 0) {
+            if (p > 0) v = std::min(std::min(v, p), std::min(q, rmax));
+            else v = std::min(v, std::min(q, rmax));
+        } else {
+            if (p > 0) v = std::min(v, std::min(p, rmax));
+            else v = std::min(v, rmax);
+        }
+        out[i] = v;
+    }
+    return TTN_OK;
+}
+
+// ---- ttn_tt ---------------------------------------------------------------------------------------
+int ttn_tt_create(int64_t d, const int64_t* dims, const int64_t* cap_rks, int64_t batch, ttn_tt_t* out) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!dims || !cap_rks || !out || d < 1 || batch < 1) return fail(TTN_ERR_ARG, "ttn_tt_create: bad argument");
+    for (int64_t k = 0; k < d; ++k) if (dims[k] < 1) return fail(TTN_ERR_ARG, "ttn_tt_create: dims must be >= 1");
+    for (int64_t k = 0; k <= d; ++k) if (cap_rks[k] < 1) return fail(TTN_ERR_ARG, "ttn_tt_create: ranks must be >= 1");
+    ttn_tt_s* h = new ttn_tt_s();
+    h->d = (int)d; h->batch = (int)batch;
+    h->dims.assign(dims, dims + d);
+    h->cap.assign(cap_rks, cap_rks + d + 1);
+    h->bound.assign(d + 1, 1);          // every train starts as the rank-1 zero train
+    h->off.resize(d + 1);
+    long long o = 0;
+    for (int64_t k = 0; k < d; ++k) {
+        h->off[k] = o;
+        long long sz = (long long)dims[k] * cap_rks[k] * cap_rks[k + 1];
+        sz = (sz + 1) & ~1LL;      // keep every slot 16-byte aligned
+        o += sz;
+    }
+    h->off[d] = o;
+    h->stride = o;
+    h->ot.assign((size_t)batch * d, 0);
+    std::vector<int> idims(d);
+    for (int64_t k = 0; k < d; ++k) idims[k] = (int)dims[k];
+    std::vector<long long> cap64(cap_rks, cap_rks + d + 1);
+    std::vector<long long> rk0((size_t)batch * (d + 1));
+    for (int64_t b = 0; b < batch; ++b) for (int64_t m = 0; m <= d; ++m) rk0[b * (d + 1) + m] = 1;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&h->d_data, sizeof(double) * (size_t)o * batch)) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_off, sizeof(long long) * (d + 1))) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_cap, sizeof(long long) * (d + 1))) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_rks, sizeof(long long) * (size_t)batch * (d + 1))) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_dims, sizeof(int) * d)) != hipSuccess) {
+        ttn_tt_free(h);
+        return hipfail(e, "hipMalloc(ttn_tt)");
+    }
+    HIPCHK(hipMemcpyAsync(h->d_off, h->off.data(), sizeof(long long) * (d + 1), hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(h->d_cap, cap64.data(), sizeof(long long) * (d + 1), hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(h->d_rks, rk0.data(), sizeof(long long) * rk0.size(), hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(h->d_dims, idims.data(), sizeof(int) * d, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemsetAsync(h->d_data, 0, sizeof(double) * (size_t)o * batch, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    *out = h;
+    return TTN_OK;
+}
+
+int ttn_tt_free(ttn_tt_t h) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!h) return TTN_OK;
+    if (g_init) hipStreamSynchronize(g_stream);
+    if (h->d_data) hipFree(h->d_data);
+    if (h->d_off) hipFree(h->d_off);
+    if (h->d_cap) hipFree(h->d_cap);
+    if (h->d_rks) hipFree(h->d_rks);
+    if (h->d_dims) hipFree(h->d_dims);
+    if (h->d_sv) hipFree(h->d_sv);
+    delete h;
+    return TTN_OK;
+}
+
+int ttn_tt_batch(ttn_tt_t h, int64_t* batch) {
+    if (!h || !batch) return fail(TTN_ERR_ARG, "null pointer");
+    *batch = h->batch;
+    return TTN_OK;
+}
+
+int ttn_tt_upload(ttn_tt_t h, int64_t b, const double* const* cores, const int64_t* rks, const int64_t* ot) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!h || !cores || !rks || b < 0 || b >= h->batch) return fail(TTN_ERR_ARG, "ttn_tt_upload: bad argument");
+    const int d = h->d;
+    for (int m = 0; m <= d; ++m) {
+        if (rks[m] < 1) return fail(TTN_ERR_ARG, "ttn_tt_upload: ranks must be >= 1");
+        if (rks[m] > h->cap[m]) return fail(TTN_ERR_CAPACITY, "ttn_tt_upload: rank exceeds the handle's capacity");
+    }
+    std::vector<long long> r64(rks, rks + d + 1);
+    HIPCHK(hipMemcpyAsync(h->d_rks + (size_t)b * (d + 1), r64.data(), sizeof(long long) * (d + 1), hipMemcpyHostToDevice, g_stream));
+    for (int k = 0; k < d; ++k) {
+        if (!cores[k]) return fail(TTN_ERR_ARG, "ttn_tt_upload: null core");
+        const size_t sz = (size_t)h->dims[k] * rks[k] * rks[k + 1];
+        HIPCHK(hipMemcpyAsync(h->d_data + (size_t)b * h->stride + h->off[k], cores[k], sizeof(double) * sz, hipMemcpyHostToDevice, g_stream));
+    }
+    HIPCHK(hipStreamSynchronize(g_stream));   // host buffers may be released by the caller
+    for (int k = 0; k < d; ++k) h->ot[(size_t)b * d + k] = ot ? ot[k] : 0;
+    // host-side upper bound on the current ranks of any train of the batch
+    for (int m = 0; m <= d; ++m) h->bound[m] = (h->batch == 1) ? rks[m] : std::max<int64_t>(h->bound[m], rks[m]);
+    return TTN_OK;
+}
+
+int ttn_tt_replicate(ttn_tt_t h, int64_t src_b) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!h || src_b < 0 || src_b >= h->batch) return fail(TTN_ERR_ARG, "ttn_tt_replicate: bad argument");
+    if (h->batch > 1) {
+        dim3 grid((unsigned)std::min<long long>((h->stride + TTN_STREAM_TB - 1) / TTN_STREAM_TB, 1024), (unsigned)h->batch);
+        hipLaunchKernelGGL(k_replicate, grid, dim3(TTN_STREAM_TB), 0, g_stream, h->dev(), (int)src_b);
+        HIPCHK(hipGetLastError());
+    }
+    for (int b = 0; b < h->batch; ++b)
+        for (int k = 0; k < h->d; ++k) h->ot[(size_t)b * h->d + k] = h->ot[(size_t)src_b * h->d + k];
+    return TTN_OK;
+}
+
+int ttn_tt_ranks(ttn_tt_t h, int64_t b, int64_t* rks, int64_t* ot) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!h || b < 0 || b >= h->batch) return fail(TTN_ERR_ARG, "ttn_tt_ranks: bad argument");
+    const int d = h->d;
+    if (rks) {
+        std::vector<long long> r64(d + 1);
+        HIPCHK(hipMemcpyAsync(r64.data(), h->d_rks + (size_t)b * (d + 1), sizeof(long long) * (d + 1), hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        for (int m = 0; m <= d; ++m) rks[m] = r64[m];
+    }
+    if (ot) for (int k = 0; k < d; ++k) ot[k] = h->ot[(size_t)b * d + k];
+    return TTN_OK;
+}
+
+int ttn_tt_download(ttn_tt_t h, int64_t b, double* const* cores) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!h || !cores || b < 0 || b >= h->batch) return fail(TTN_ERR_ARG, "ttn_tt_download: bad argument");
+    const int d = h->d;
+    std::vector<long long> r64(d + 1);
+    HIPCHK(hipMemcpyAsync(r64.data(), h->d_rks + (size_t)b * (d + 1), sizeof(long long) * (d + 1), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (int k = 0; k < d; ++k) {
+        if (!cores[k]) return fail(TTN_ERR_ARG, "ttn_tt_download: null core");
+        const size_t sz = (size_t)h->dims[k] * r64[k] * r64[k + 1];
+        HIPCHK(hipMemcpyAsync(cores[k], h->d_data + (size_t)b * h->stride + h->off[k], sizeof(double) * sz, hipMemcpyDeviceToHost, g_stream));
+    }
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return TTN_OK;
+}
+
+int ttn_tt_copy(ttn_tt_t dst, ttn_tt_t src) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!dst || !src) return fail(TTN_ERR_ARG, "null handle");
+    if (!same_dims(dst->dims, src->dims) || dst->batch != src->batch) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    for (int m = 0; m <= src->d; ++m) if (dst->cap[m] < src->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_tt_copy: destination capacity too small");
+    // scale kernel with a = 1 on core -1 is a plain per-core copy that honours the two slot layouts
+    const int d = src->d;
+    long long maxsz = 0;
+    for (int k = 0; k < d; ++k) maxsz = std::max<long long>(maxsz, (long long)src->dims[k] * src->bound[k] * src->bound[k + 1]);
+    hipLaunchKernelGGL(k_ranks_copy, dim3(src->batch), dim3(64), 0, g_stream, dst->dev(), src->dev());
+    dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((maxsz + TTN_STREAM_TB - 1) / TTN_STREAM_TB, 2048)), (unsigned)d, (unsigned)src->batch);
+    hipLaunchKernelGGL(k_scale, grid, dim3(TTN_STREAM_TB), 0, g_stream, src->dev(), dst->dev(), 1.0, -1, 0);
+    HIPCHK(hipGetLastError());
+    dst->bound = src->bound;
+    dst->ot = src->ot;
+    return TTN_OK;
+}
+
+// ---- ttn_tto --------------------------------------------------------------------------------------
+int ttn_tto_create(int64_t d, const int64_t* dims, const int64_t* rks, const double* const* cores, ttn_tto_t* out) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!dims || !rks || !cores || !out || d < 1) return fail(TTN_ERR_ARG, "ttn_tto_create: bad argument");
+    ttn_tto_s* h = new ttn_tto_s();
+    h->d = (int)d;
+    h->dims.assign(dims, dims + d);
+    h->rks.assign(rks, rks + d + 1);
+    h->off.resize(d + 1);
+    long long o = 0;
+    for (int64_t k = 0; k < d; ++k) {
+        h->off[k] = o;
+        long long sz = (long long)dims[k] * dims[k] * rks[k] * rks[k + 1];
+        sz = (sz + 1) & ~1LL;
+        o += sz;
+    }
+    h->off[d] = o;
+    std::vector<double> flat((size_t)o, 0.0);
+    for (int64_t k = 0; k < d; ++k) {
+        if (!cores[k]) { delete h; return fail(TTN_ERR_ARG, "ttn_tto_create: null core"); }
+        std::memcpy(flat.data() + h->off[k], cores[k], sizeof(double) * (size_t)dims[k] * dims[k] * rks[k] * rks[k + 1]);
+    }
+    std::vector<int> idims(d);
+    for (int64_t k = 0; k < d; ++k) idims[k] = (int)dims[k];
+    std::vector<long long> r64(rks, rks + d + 1);
+    hipError_t e;
+    if ((e = hipMalloc((void**)&h->d_data, sizeof(double) * (size_t)std::max<long long>(o, 1))) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_off, sizeof(long long) * (d + 1))) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_rks, sizeof(long long) * (d + 1))) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_dims, sizeof(int) * d)) != hipSuccess) {
+        ttn_tto_free(h);
+        return hipfail(e, "hipMalloc(ttn_tto)");
+    }
+    HIPCHK(hipMemcpyAsync(h->d_data, flat.data(), sizeof(double) * (size_t)o, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(h->d_off, h->off.data(), sizeof(long long) * (d + 1), hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(h->d_rks, r64.data(), sizeof(long long) * (d + 1), hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(h->d_dims, idims.data(), sizeof(int) * d, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    *out = h;
+    return TTN_OK;
+}
+
+int ttn_tto_free(ttn_tto_t h) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!h) return TTN_OK;
+    if (g_init) hipStreamSynchronize(g_stream);
+    if (h->d_data) hipFree(h->d_data);
+    if (h->d_off) hipFree(h->d_off);
+    if (h->d_rks) hipFree(h->d_rks);
+    if (h->d_dims) hipFree(h->d_dims);
+    delete h;
+    return TTN_OK;
+}
+
+// ---- streaming ops --------------------------------------------------------------------------------
+static dim3 stream_grid(long long max_items, int d, int batch) {
+    long long gx = (max_items + TTN_STREAM_TB - 1) / TTN_STREAM_TB;
+    gx = std::max<long long>(1, std::min<long long>(gx, 4096));
+    return dim3((unsigned)gx, (unsigned)d, (unsigned)batch);
+}
+
+int ttn_apply(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!A || !x || !y) return fail(TTN_ERR_ARG, "null handle");
+    if (!same_dims(A->dims, x->dims) || !same_dims(x->dims, y->dims)) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    if (x->batch != y->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
+    if (x == y) return fail(TTN_ERR_ARG, "ttn_apply: output must not alias the input");
+    const int d = x->d;
+    long long maxpq = 0;
+    for (int m = 0; m <= d; ++m) if (y->cap[m] < A->rks[m] * x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_apply: destination capacity too small");
+    for (int k = 0; k < d; ++k) maxpq = std::max<long long>(maxpq, (long long)A->rks[k] * x->bound[k] * A->rks[k + 1] * x->bound[k + 1]);
+    hipLaunchKernelGGL(k_ranks_mul_op, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), A->dev(), x->dev());
+    hipLaunchKernelGGL(k_apply, stream_grid(maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, A->dev(), x->dev(), y->dev());
+    HIPCHK(hipGetLastError());
+    for (int m = 0; m <= d; ++m) y->bound[m] = A->rks[m] * x->bound[m];
+    std::fill(y->ot.begin(), y->ot.end(), 0);     // zeros_tt (tt_operations.jl:103)
+    return TTN_OK;
+}
+
+int ttn_hadamard(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!x || !y || !z) return fail(TTN_ERR_ARG, "null handle");
+    if (!same_dims(x->dims, y->dims) || !same_dims(x->dims, z->dims)) return fail(TTN_ERR_DIMS, "Incompatible TT dimensions");
+    if (x->batch != y->batch || x->batch != z->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
+    if (z == x || z == y) return fail(TTN_ERR_ARG, "ttn_hadamard: output must not alias an input");
+    const int d = x->d;
+    long long maxpq = 0;
+    for (int m = 0; m <= d; ++m) if (z->cap[m] < x->bound[m] * y->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_hadamard: destination capacity too small");
+    for (int k = 0; k < d; ++k) maxpq = std::max<long long>(maxpq, (long long)x->bound[k] * y->bound[k] * x->bound[k + 1] * y->bound[k + 1]);
+    hipLaunchKernelGGL(k_ranks_mul, dim3(x->batch), dim3(64), 0, g_stream, z->dev(), x->dev(), y->dev());
+    hipLaunchKernelGGL(k_hadamard, stream_grid(maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), z->dev());
+    HIPCHK(hipGetLastError());
+    for (int m = 0; m <= d; ++m) z->bound[m] = x->bound[m] * y->bound[m];
+    std::fill(z->ot.begin(), z->ot.end(), 0);
+    return TTN_OK;
+}
+
+int ttn_add(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!x || !y || !z) return fail(TTN_ERR_ARG, "null handle");
+    if (!same_dims(x->dims, y->dims) || !same_dims(x->dims, z->dims)) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    if (x->batch != y->batch || x->batch != z->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
+    if (z == x || z == y) return fail(TTN_ERR_ARG, "ttn_add: output must not alias an input");
+    const int d = x->d;
+    if (d < 2) return fail(TTN_ERR_UNSUPPORTED, "ttn_add: the reference's + is only defined for d >= 2");
+    std::vector<int64_t> zb(d + 1);
+    for (int m = 0; m <= d; ++m) zb[m] = (m == 0 || m == d) ? 1 : x->bound[m] + y->bound[m];
+    long long maxpq = 0;
+    for (int m = 0; m <= d; ++m) if (z->cap[m] < zb[m]) return fail(TTN_ERR_CAPACITY, "ttn_add: destination capacity too small");
+    for (int k = 0; k < d; ++k) maxpq = std::max<long long>(maxpq, (long long)zb[k] * zb[k + 1]);
+    hipLaunchKernelGGL(k_ranks_add, dim3(x->batch), dim3(64), 0, g_stream, z->dev(), x->dev(), y->dev());
+    hipLaunchKernelGGL(k_add, stream_grid(maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), z->dev());
+    HIPCHK(hipGetLastError());
+    z->bound = zb;
+    std::fill(z->ot.begin(), z->ot.end(), 0);
+    return TTN_OK;
+}
+
+int ttn_scale(double a, ttn_tt_t x, ttn_tt_t y) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!x || !y) return fail(TTN_ERR_ARG, "null handle");
+    if (!same_dims(x->dims, y->dims) || x->batch != y->batch) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    const int d = x->d;
+    for (int m = 0; m <= d; ++m) if (y->cap[m] < x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_scale: destination capacity too small");
+    // i = findfirst(==(0), ot), else 1  (tt_operations.jl:262); all trains of a batch share ot by construction
+    int which = 0;
+    for (int k = 0; k < d; ++k) if (x->ot[k] == 0) { which = k; break; }
+    long long maxsz = 0;
+    for (int k = 0; k < d; ++k) maxsz = std::max<long long>(maxsz, (long long)x->dims[k] * x->bound[k] * x->bound[k + 1]);
+    if (x != y) hipLaunchKernelGGL(k_ranks_copy, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), x->dev());
+    hipLaunchKernelGGL(k_scale, stream_grid(maxsz, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), a, which, a == 0.0 ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    y->bound = x->bound;
+    if (a == 0.0) std::fill(y->ot.begin(), y->ot.end(), 0); else y->ot = x->ot;
+    return TTN_OK;
+}
+
+// ---- dense ops ------------------------------------------------------------------------------------
+static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, double truncerr, int64_t sweeps) {
+    const int d = psi->d;
+    if (d < 2 && k_single == 0) return TTN_OK;
+    // bounds on merged-matrix sides from the host rank bounds
+    long long pmax = 1, qmax = 1;
+    for (int k = 0; k + 1 < d; ++k) {
+        const long long mr = psi->dims[k] * psi->bound[k], mc = psi->dims[k + 1] * psi->bound[k + 2];
+        pmax = std::max(pmax, std::min(mr, mc));
+        qmax = std::max(qmax, std::max(mr, mc));
+    }
+    if (pmax > 4096 || qmax > 16384) return fail(TTN_ERR_UNSUPPORTED, "ttn_compress: merged matrix larger than 4096 x 16384");
+    const long long per_train = 2 * pmax * qmax + QR_NB * qmax + pmax * QR_NB + 2 * pmax * pmax + 4 * pmax + 64;
+    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * psi->batch);
+    if (rc) return rc;
+    rc = ensure_batch_bufs(psi->batch);
+    if (rc) return rc;
+    const int steps = k_single ? 1 : (int)(2 * (d - 1) * sweeps);
+    if (psi->sv_on) {
+        if (psi->sv_steps < steps || psi->sv_pmax < pmax) {
+            if (psi->d_sv) { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipFree(psi->d_sv)); psi->d_sv = nullptr; }
+            HIPCHK(hipMalloc((void**)&psi->d_sv, sizeof(double) * (size_t)psi->batch * steps * pmax));
+        }
+        psi->sv_steps = steps;
+        psi->sv_pmax = (int)pmax;
+    }
+    CompressArgs P;
+    P.tt = psi->dev();
+    P.max_bond = max_bond;
+    P.truncerr = truncerr;
+    P.sweeps = (int)sweeps;
+    P.k_single = (int)k_single;
+    P.scratch = (double*)g_scratch;
+    P.scratch_stride = per_train;
+    P.pmax = (int)pmax; P.qmax = (int)qmax;
+    P.sv_out = psi->sv_on ? psi->d_sv : nullptr;
+    P.sv_steps = steps;
+    P.status = g_status;
+    P.sweep_stats = g_status + psi->batch;
+    hipLaunchKernelGGL(k_compress, dim3(psi->batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, P);
+    HIPCHK(hipGetLastError());
+    // host rank bounds after truncation
+    if (k_single) {
+        psi->bound[k_single] = std::min<int64_t>(psi->bound[k_single], max_bond);
+    } else {
+        for (int m = 1; m < d; ++m) psi->bound[m] = std::min<int64_t>(psi->bound[m], max_bond);
+    }
+    return TTN_OK;
+}
+
+int ttn_compress(ttn_tt_t psi, int64_t max_bond, double truncerr, int64_t sweeps) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!psi) return fail(TTN_ERR_ARG, "null handle");
+    if (sweeps < 1) return fail(TTN_ERR_SWEEPS, "sweeps must be >= 1");
+    if (max_bond < 1) return fail(TTN_ERR_ARG, "max_bond must be >= 1");
+    return launch_compress(psi, 0, max_bond, truncerr, sweeps);
+}
+
+int ttn_bond_truncate(ttn_tt_t psi, int64_t k, int64_t max_bond, double truncerr) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!psi) return fail(TTN_ERR_ARG, "null handle");
+    if (k < 1 || k >= psi->d) return fail(TTN_ERR_BOND_INDEX, "k must be in 1:(N-1)");
+    if (max_bond < 1) return fail(TTN_ERR_ARG, "max_bond must be >= 1");
+    return launch_compress(psi, k, max_bond, truncerr, 1);
+}
+
+int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (sweeps < 1) return fail(TTN_ERR_SWEEPS, "sweeps must be >= 1");
+    int rc = ttn_apply(A, x, y);
+    if (rc) return rc;
+    return ttn_compress(y, max_bond, truncerr, sweeps);
+}
+
+// status of the last dense kernel (synchronises): returns TTN_ERR_NO_CONVERGENCE if any train failed
+static int check_status(int batch) {
+    std::vector<int> st(batch);
+    HIPCHK(hipMemcpyAsync(st.data(), g_status, sizeof(int) * batch, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (int b = 0; b < batch; ++b) if (st[b]) return fail(TTN_ERR_NO_CONVERGENCE, "Jacobi SVD hit its sweep limit");
+    return TTN_OK;
+}
+
+int ttn_compress_status(ttn_tt_t psi, int64_t* total_jacobi_sweeps) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!psi) return fail(TTN_ERR_ARG, "null handle");
+    if (psi->batch > g_status_cap) return fail(TTN_ERR_ARG, "no dense kernel has run for this batch size");
+    if (total_jacobi_sweeps) {
+        std::vector<int> st(psi->batch);
+        HIPCHK(hipMemcpyAsync(st.data(), g_status + psi->batch, sizeof(int) * psi->batch, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        for (int b = 0; b < psi->batch; ++b) total_jacobi_sweeps[b] = st[b];
+    }
+    return check_status(psi->batch);
+}
+
+int ttn_dot(ttn_tt_t a, ttn_tt_t b, double* out) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!a || !b || !out) return fail(TTN_ERR_ARG, "null pointer");
+    if (!same_dims(a->dims, b->dims)) return fail(TTN_ERR_DIMS, "TT dimensions are not compatible");
+    if (a->batch != b->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
+    const int d = a->d;
+    long long ramax = 1, rbmax = 1, nmax = 1;
+    for (int m = 0; m <= d; ++m) { ramax = std::max<long long>(ramax, a->bound[m]); rbmax = std::max<long long>(rbmax, b->bound[m]); }
+    for (int k = 0; k < d; ++k) nmax = std::max<long long>(nmax, a->dims[k]);
+    const long long per_train = (2 + nmax) * ramax * rbmax + 16;
+    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * a->batch);
+    if (rc) return rc;
+    rc = ensure_batch_bufs(a->batch);
+    if (rc) return rc;
+    DotArgs P;
+    P.a = a->dev(); P.b = b->dev();
+    P.scratch = (double*)g_scratch; P.scratch_stride = per_train;
+    P.ramax = (int)ramax; P.rbmax = (int)rbmax; P.nmax = (int)nmax;
+    P.out = g_dout;
+    hipLaunchKernelGGL(k_dot, dim3(a->batch), dim3(TTN_WG), sizeof(double) * GEMM_LDS_DOUBLES, g_stream, P);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, g_dout, sizeof(double) * a->batch, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return TTN_OK;
+}
+
+int ttn_norm(ttn_tt_t a, double* out) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = ttn_dot(a, a, out);
+    if (rc) return rc;
+    for (int b = 0; b < a->batch; ++b) { double v = out[b]; v = v < 0 ? 0.0 : v; out[b] = std::sqrt(v); }
+    return TTN_OK;
+}
+
+int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!x || !y) return fail(TTN_ERR_ARG, "null handle");
+    if (!same_dims(x->dims, y->dims) || x->batch != y->batch) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    if (x == y) return fail(TTN_ERR_ARG, "ttn_orthogonalize: output must not alias the input");
+    const int d = x->d;
+    if (center < 1 || center > d) return fail(TTN_ERR_CENTER, "Impossible orthogonalization");
+    // y ranks start from r_and_d_to_rks(x.rks, dims) and can only shrink
+    std::vector<int64_t> yb(d + 1);
+    ttn_r_and_d_to_rks(d, x->dims.data(), d + 1, x->bound.data(), 1024, yb.data());
+    for (int m = 0; m <= d; ++m) if (y->cap[m] < yb[m]) return fail(TTN_ERR_CAPACITY, "ttn_orthogonalize: destination capacity too small");
+    long long rmax = 1, nmax = 1;
+    for (int m = 0; m <= d; ++m) rmax = std::max<long long>(rmax, x->bound[m]);
+    for (int k = 0; k < d; ++k) nmax = std::max<long long>(nmax, x->dims[k]);
+    const long long mm = nmax * rmax;           // rows of the tall matrices
+    const long long per_train = 2 * mm * rmax + 4 * rmax * rmax + rmax + 64;   // Tm, Qb, 4 R buffers, taus
+    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * x->batch);
+    if (rc) return rc;
+    rc = ensure_batch_bufs(x->batch);
+    if (rc) return rc;
+    OrthoArgs P;
+    P.x = x->dev(); P.y = y->dev();
+    P.center = (int)center - 1;
+    P.scratch = (double*)g_scratch; P.scratch_stride = per_train;
+    P.mmax = (int)mm; P.rmax = (int)rmax;
+    hipLaunchKernelGGL(k_orthogonalize, dim3(x->batch), dim3(TTN_WG), ORTHO_LDS_BYTES, g_stream, P);
+    HIPCHK(hipGetLastError());
+    y->bound = yb;
+    for (int b = 0; b < y->batch; ++b)
+        for (int k = 0; k < d; ++k) y->ot[(size_t)b * d + k] = (k < center - 1) ? 1 : (k > center - 1 ? -1 : 0);
+    return TTN_OK;
+}
+
+// ---- singular-value capture -----------------------------------------------------------------------
+int ttn_sv_capture(ttn_tt_t h, int enable) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!h) return fail(TTN_ERR_ARG, "null handle");
+    h->sv_on = enable != 0;
+    return TTN_OK;
+}
+int ttn_sv_get(ttn_tt_t h, int64_t b, int64_t step, double* out, int64_t cap, int64_t* n) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!h || !out || !n || b < 0 || b >= h->batch) return fail(TTN_ERR_ARG, "bad argument");
+    if (!h->d_sv || step < 0 || step >= h->sv_steps) return fail(TTN_ERR_ARG, "no captured singular values for that step");
+    std::vector<double> tmp(h->sv_pmax);
+    HIPCHK(hipMemcpyAsync(tmp.data(), h->d_sv + ((size_t)b * h->sv_steps + step) * h->sv_pmax, sizeof(double) * h->sv_pmax, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    int64_t cnt = 0;
+    for (int i = 0; i < h->sv_pmax && tmp[i] >= 0.0; ++i) { if (cnt < cap) out[cnt] = tmp[i]; ++cnt; }
+    *n = std::min(cnt, cap);
+    return TTN_OK;
+}
+
+// ---- stateless host-pointer entry points ----------------------------------------------------------
+namespace {
+struct TmpTT {
+    ttn_tt_t h = nullptr;
+    ~TmpTT() { if (h) ttn_tt_free(h); }
+};
+struct TmpTTO {
+    ttn_tto_t h = nullptr;
+    ~TmpTTO() { if (h) ttn_tto_free(h); }
+};
+int auto_init() {
+    if (g_init) return TTN_OK;
+    return ttn_init(0);
+}
+}  // namespace
+
+int ttn_apply_f64(int64_t d, const int64_t* dims, const double* const* A_cores, const int64_t* A_rks,
+                  const double* const* X_cores, const int64_t* X_rks, double* const* Y_cores) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = auto_init(); if (rc) return rc;
+    if (!dims || !A_cores || !A_rks || !X_cores || !X_rks || !Y_cores || d < 1) return fail(TTN_ERR_ARG, "bad argument");
+    TmpTTO A; TmpTT x, y;
+    if ((rc = ttn_tto_create(d, dims, A_rks, A_cores, &A.h))) return rc;
+    if ((rc = ttn_tt_create(d, dims, X_rks, 1, &x.h))) return rc;
+    if ((rc = ttn_tt_upload(x.h, 0, X_cores, X_rks, nullptr))) return rc;
+    std::vector<int64_t> yr(d + 1);
+    for (int64_t m = 0; m <= d; ++m) yr[m] = A_rks[m] * X_rks[m];
+    if ((rc = ttn_tt_create(d, dims, yr.data(), 1, &y.h))) return rc;
+    if ((rc = ttn_apply(A.h, x.h, y.h))) return rc;
+    return ttn_tt_download(y.h, 0, Y_cores);
+}
+
+int ttn_dot_f64(int64_t d, const int64_t* dims, const double* const* A_cores, const int64_t* A_rks,
+                const double* const* B_cores, const int64_t* B_rks, double* out) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = auto_init(); if (rc) return rc;
+    if (!dims || !A_cores || !A_rks || !B_cores || !B_rks || !out || d < 1) return fail(TTN_ERR_ARG, "bad argument");
+    TmpTT a, b;
+    if ((rc = ttn_tt_create(d, dims, A_rks, 1, &a.h))) return rc;
+    if ((rc = ttn_tt_upload(a.h, 0, A_cores, A_rks, nullptr))) return rc;
+    if ((rc = ttn_tt_create(d, dims, B_rks, 1, &b.h))) return rc;
+    if ((rc = ttn_tt_upload(b.h, 0, B_cores, B_rks, nullptr))) return rc;
+    return ttn_dot(a.h, b.h, out);
+}
+
+int ttn_hadamard_f64(int64_t d, const int64_t* dims, const double* const* X_cores, const int64_t* X_rks,
+                     const double* const* Y_cores, const int64_t* Y_rks, double* const* Z_cores) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = auto_init(); if (rc) return rc;
+    if (!dims || !X_cores || !X_rks || !Y_cores || !Y_rks || !Z_cores || d < 1) return fail(TTN_ERR_ARG, "bad argument");
+    TmpTT x, y, z;
+    std::vector<int64_t> zr(d + 1);
+    for (int64_t m = 0; m <= d; ++m) zr[m] = X_rks[m] * Y_rks[m];
+    if ((rc = ttn_tt_create(d, dims, X_rks, 1, &x.h))) return rc;
+    if ((rc = ttn_tt_upload(x.h, 0, X_cores, X_rks, nullptr))) return rc;
+    if ((rc = ttn_tt_create(d, dims, Y_rks, 1, &y.h))) return rc;
+    if ((rc = ttn_tt_upload(y.h, 0, Y_cores, Y_rks, nullptr))) return rc;
+    if ((rc = ttn_tt_create(d, dims, zr.data(), 1, &z.h))) return rc;
+    if ((rc = ttn_hadamard(x.h, y.h, z.h))) return rc;
+    return ttn_tt_download(z.h, 0, Z_cores);
+}
+
+int ttn_add_f64(int64_t d, const int64_t* dims, const double* const* X_cores, const int64_t* X_rks,
+                const double* const* Y_cores, const int64_t* Y_rks, double* const* Z_cores) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = auto_init(); if (rc) return rc;
+    if (!dims || !X_cores || !X_rks || !Y_cores || !Y_rks || !Z_cores || d < 1) return fail(TTN_ERR_ARG, "bad argument");
+    TmpTT x, y, z;
+    std::vector<int64_t> zr(d + 1);
+    for (int64_t m = 0; m <= d; ++m) zr[m] = (m == 0 || m == d) ? 1 : X_rks[m] + Y_rks[m];
+    if ((rc = ttn_tt_create(d, dims, X_rks, 1, &x.h))) return rc;
+    if ((rc = ttn_tt_upload(x.h, 0, X_cores, X_rks, nullptr))) return rc;
+    if ((rc = ttn_tt_create(d, dims, Y_rks, 1, &y.h))) return rc;
+    if ((rc = ttn_tt_upload(y.h, 0, Y_cores, Y_rks, nullptr))) return rc;
+    if ((rc = ttn_tt_create(d, dims, zr.data(), 1, &z.h))) return rc;
+    if ((rc = ttn_add(x.h, y.h, z.h))) return rc;
+    return ttn_tt_download(z.h, 0, Z_cores);
+}
+
+int ttn_scale_f64(int64_t d, const int64_t* dims, double a, const double* const* X_cores, const int64_t* X_rks,
+                  const int64_t* X_ot, double* const* Y_cores, int64_t* Y_ot) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = auto_init(); if (rc) return rc;
+    if (!dims || !X_cores || !X_rks || !Y_cores || d < 1) return fail(TTN_ERR_ARG, "bad argument");
+    TmpTT x, y;
+    if ((rc = ttn_tt_create(d, dims, X_rks, 1, &x.h))) return rc;
+    if ((rc = ttn_tt_upload(x.h, 0, X_cores, X_rks, X_ot))) return rc;
+    if ((rc = ttn_tt_create(d, dims, X_rks, 1, &y.h))) return rc;
+    if ((rc = ttn_scale(a, x.h, y.h))) return rc;
+    if (Y_ot) ttn_tt_ranks(y.h, 0, nullptr, Y_ot);
+    return ttn_tt_download(y.h, 0, Y_cores);
+}
+
+int ttn_orthogonalize_f64(int64_t d, const int64_t* dims, const double* const* X_cores, const int64_t* X_rks, int64_t center,
+                          double* const* Y_cores, int64_t* Y_rks, int64_t* Y_ot) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = auto_init(); if (rc) return rc;
+    if (!dims || !X_cores || !X_rks || !Y_cores || !Y_rks || !Y_ot || d < 1) return fail(TTN_ERR_ARG, "bad argument");
+    if (center < 1 || center > d) return fail(TTN_ERR_CENTER, "Impossible orthogonalization");
+    TmpTT x, y;
+    std::vector<int64_t> yr(d + 1);
+    ttn_r_and_d_to_rks(d, dims, d + 1, X_rks, 1024, yr.data());
+    if ((rc = ttn_tt_create(d, dims, X_rks, 1, &x.h))) return rc;
+    if ((rc = ttn_tt_upload(x.h, 0, X_cores, X_rks, nullptr))) return rc;
+    if ((rc = ttn_tt_create(d, dims, yr.data(), 1, &y.h))) return rc;
+    if ((rc = ttn_orthogonalize(x.h, center, y.h))) return rc;
+    if ((rc = ttn_tt_ranks(y.h, 0, Y_rks, Y_ot))) return rc;
+    return ttn_tt_download(y.h, 0, Y_cores);
+}
+
+static int compress_host(int64_t d, const int64_t* dims, double* const* cores, int64_t* rks, int64_t k, int64_t max_bond,
+                         double truncerr, int64_t sweeps) {
+    int rc = auto_init(); if (rc) return rc;
+    if (!dims || !cores || !rks || d < 1) return fail(TTN_ERR_ARG, "bad argument");
+    TmpTT x;
+    if ((rc = ttn_tt_create(d, dims, rks, 1, &x.h))) return rc;
+    if ((rc = ttn_tt_upload(x.h, 0, cores, rks, nullptr))) return rc;
+    if (k > 0) rc = ttn_bond_truncate(x.h, k, max_bond, truncerr);
+    else rc = ttn_compress(x.h, max_bond, truncerr, sweeps);
+    if (rc) return rc;
+    if ((rc = ttn_compress_status(x.h, nullptr))) return rc;
+    if ((rc = ttn_tt_ranks(x.h, 0, rks, nullptr))) return rc;
+    return ttn_tt_download(x.h, 0, cores);
+}
+
+int ttn_compress_f64(int64_t d, const int64_t* dims, double* const* cores, int64_t* rks, int64_t max_bond, double truncerr,
+                     int64_t sweeps) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (sweeps < 1) return fail(TTN_ERR_SWEEPS, "sweeps must be >= 1");
+    return compress_host(d, dims, cores, rks, 0, max_bond, truncerr, sweeps);
+}
+
+int ttn_bond_truncate_f64(int64_t d, const int64_t* dims, double* const* cores, int64_t* rks, int64_t k, int64_t max_bond,
+                          double truncerr) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (k < 1 || k >= d) return fail(TTN_ERR_BOND_INDEX, "k must be in 1:(N-1)");
+    return compress_host(d, dims, cores, rks, k, max_bond, truncerr, 1);
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// ttn_common.h — shared host/device declarations of libttn_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TTN_WG 1024            // threads of the dense (one-workgroup-per-train) kernels
+#define TTN_MAX_D 64           // max chain length handled by the on-stack tables of the host API
+#define TTN_SV_NONE (-1)
+
+// Device view of one batch of TT vectors (see include/ttn.h: ttn_tt).
+struct TTDev {
+    double*        data;      // arena: train b, core k at data + b*stride + off[k]
+    long long      stride;    // doubles per train
+    const long long* off;     // [d+1] device, slot offsets from CAPACITY ranks
+    long long*     rks;       // [batch][d+1] device, current ranks
+    const int*     dims;      // [d] device
+    const long long* cap;     // [d+1] device, capacity ranks
+    int            d;
+    int            batch;
+};
+
+// Device view of one TT operator.
+struct TTODev {
+    const double*  data;
+    const long long* off;     // [d+1] device
+    const long long* rks;     // [d+1] device
+    const int*     dims;      // [d] device
+    int            d;
+};
+
+// A 2-level strided index: idx(i) = q ? (i % q)*lo + (i / q)*hi : i*lo.
+// Lets a TT core (n, rl, rr) be read as the matrices the reference forms with
+// permutedims+reshape (src/tt_tools.jl:746-752) without any copy.
+struct Idx {
+    int q;
+    long long lo, hi;
+};
+struct View {
+    double* p;
+    Idx r, c;
+};
+
+__host__ __device__ inline long long ix(const Idx& d, int i) {
+    return d.q ? (long long)(i % d.q) * d.lo + (long long)(i / d.q) * d.hi : (long long)i * d.lo;
+}
+__host__ __device__ inline Idx plain(long long stride) { return Idx{0, stride, 0}; }
+__host__ __device__ inline View tview(View v) { return View{v.p, v.c, v.r}; }
+__host__ __device__ inline View mkview(double* p, Idx r, Idx c) { return View{p, r, c}; }
+__host__ __device__ inline long long minstride(const Idx& d) { return d.q ? (d.lo < d.hi ? d.lo : d.hi) : d.lo; }

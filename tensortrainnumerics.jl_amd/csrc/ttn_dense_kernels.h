@@ -1,0 +1,499 @@
+// ttn_dense_kernels.h — one-workgroup-per-train dense linear algebra for the chain recurrences:
+// tt_compress! bond steps (merge GEMM -> LQ -> one-sided Jacobi SVD -> truncate -> split),
+// dot (transfer-matrix GEMMs) and orthogonalize (Householder QR/LQ sweeps).
+//
+// Design: a sweep is strictly sequential along the chain, so ONE 1024-thread workgroup owns one
+// train for the whole sweep (no inter-workgroup synchronisation anywhere); a batch of trains fills
+// the 256 CUs.  All matrices are addressed through `View`s (2-level strides) so the reference's
+// permutedims/reshape copies (src/tt_tools.jl:746-767) become index arithmetic.
+#pragma once
+#include "ttn_common.h"
+#include <float.h>
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 16
+#define GEMM_LD 132                      // padded LDS leading dimension (doubles)
+#define GEMM_LDS_DOUBLES (2 * GEMM_BK * GEMM_LD)
+#define QR_NB 16                         // Householder panel width
+#define JACOBI_MAX_SWEEPS 40
+
+// -------------------------------------------------------------------------------------------------
+// workgroup reductions (1024 threads = 16 waves of 64)
+// -------------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// red: LDS scratch of >= 32 doubles.  All threads get the result.
+__device__ inline double wg_sum(double v, double* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    double t = (l < nw) ? red[l] : 0.0;
+    t = wave_sum(t);
+    return t;
+}
+__device__ inline double wg_max(double v, double* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    double t = (l < nw) ? red[l] : 0.0;
+    t = wave_max(t);
+    return t;
+}
+
+// -------------------------------------------------------------------------------------------------
+// wg_gemm: C[m x n] = alpha * A[m x k] * B[k x n] + beta * C, all operands through Views.
+// 128x128x16 LDS tiles, 4x4 register micro-tile per thread (1024 threads), fp64 FMA.
+// Every thread of the workgroup must call it (it contains barriers).
+// -------------------------------------------------------------------------------------------------
+__device__ void wg_gemm(int m, int n, int k, View A, View B, View C, double alpha, double beta, double* lds) {
+    const int tid = threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;
+    double* As = lds;
+    double* Bs = lds + GEMM_BK * GEMM_LD;
+    // which index runs fastest across consecutive threads when staging (pick the smaller stride)
+    const bool a_kfast = minstride(A.c) < minstride(A.r);
+    const bool b_kfast = minstride(B.r) < minstride(B.c);
+    for (int m0 = 0; m0 < m; m0 += GEMM_BM) {
+        for (int n0 = 0; n0 < n; n0 += GEMM_BN) {
+            double acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+            for (int k0 = 0; k0 < k; k0 += GEMM_BK) {
+                __syncthreads();
+                for (int e = tid; e < GEMM_BM * GEMM_BK; e += TTN_WG) {
+                    int r, kk;
+                    if (a_kfast) { kk = e & (GEMM_BK - 1); r = e >> 4; } else { r = e & (GEMM_BM - 1); kk = e >> 7; }
+                    const int gi = m0 + r, gk = k0 + kk;
+                    As[kk * GEMM_LD + r] = (gi < m && gk < k) ? A.p[ix(A.r, gi) + ix(A.c, gk)] : 0.0;
+                }
+                for (int e = tid; e < GEMM_BN * GEMM_BK; e += TTN_WG) {
+                    int c, kk;
+                    if (b_kfast) { kk = e & (GEMM_BK - 1); c = e >> 4; } else { c = e & (GEMM_BN - 1); kk = e >> 7; }
+                    const int gj = n0 + c, gk = k0 + kk;
+                    Bs[kk * GEMM_LD + c] = (gj < n && gk < k) ? B.p[ix(B.r, gk) + ix(B.c, gj)] : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < GEMM_BK; ++kk) {
+                    double a[4], b[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = As[kk * GEMM_LD + ty * 4 + i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[j] = Bs[kk * GEMM_LD + tx * 4 + j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gi = m0 + ty * 4 + i;
+                if (gi >= m) continue;
+                const long long ro = ix(C.r, gi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gj = n0 + tx * 4 + j;
+                    if (gj >= n) continue;
+                    double* cp = C.p + ro + ix(C.c, gj);
+                    double v = alpha * acc[i][j];
+                    if (beta != 0.0) v += beta * (*cp);
+                    *cp = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Householder LQ, factor only, blocked (compact WY), in place on a row-major p x q matrix (q >= p).
+// On exit the lower triangle of M2[:, 0:p] holds L with M = L*Q; Q is never formed.
+// Row reflector j: H_j = I - tau_j v_j v_j^T acting from the right, v_j = (0.., 1, M2[j, j+1:]).
+// Trailing update of a panel: C <- C - ((C V^T) T) V  (three wg_gemm calls).
+// Scratch: Vb (QR_NB x q), Wb (p x QR_NB) in global; Ts (QR_NB*QR_NB) + tau (QR_NB) + red in LDS.
+// -------------------------------------------------------------------------------------------------
+__device__ __noinline__ void wg_lq_factor(int p, int q, double* M2, int ld, double* Vb, double* Wb, double* lds_gemm,
+                             double* Ts, double* Ss, double* taus, double* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    for (int j0 = 0; j0 < p; j0 += QR_NB) {
+        const int jb = min(QR_NB, p - j0);
+        const int len = q - j0;
+        // ---- panel factorisation (rows j0..j0+jb-1, columns j0..q-1) ----
+        for (int jj = 0; jj < jb; ++jj) {
+            const int j = j0 + jj;
+            double* row = M2 + (long long)j * ld;
+            double s = 0.0;
+            for (int c = j + 1 + tid; c < q; c += TTN_WG) { const double v = row[c]; s = fma(v, v, s); }
+            const double xnorm2 = wg_sum(s, red);
+            const double alpha = row[j];
+            double tau = 0.0, scal = 0.0, beta = alpha;
+            if (xnorm2 > 0.0) {
+                beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha);
+                tau = (beta - alpha) / beta;
+                scal = 1.0 / (alpha - beta);
+            }
+            __syncthreads();           // everyone has read alpha
+            if (xnorm2 > 0.0) {
+                for (int c = j + 1 + tid; c < q; c += TTN_WG) row[c] *= scal;
+                if (tid == 0) row[j] = beta;
+            }
+            if (tid == 0) taus[jj] = tau;
+            __syncthreads();
+            if (tau != 0.0) {
+                // apply H_j to the remaining rows of the panel, one wave per row
+                for (int i = j + 1 + wave; i < j0 + jb; i += nwaves) {
+                    double* ri = M2 + (long long)i * ld;
+                    double w = 0.0;
+                    for (int c = j + 1 + lane; c < q; c += 64) w = fma(ri[c], row[c], w);
+                    w = wave_sum(w) + ri[j];
+                    const double tw = tau * w;
+                    for (int c = j + 1 + lane; c < q; c += 64) ri[c] = fma(-tw, row[c], ri[c]);
+                    if (lane == 0) ri[j] -= tw;
+                }
+            }
+            __syncthreads();
+        }
+        const int rows_t = p - (j0 + jb);
+        if (rows_t <= 0) break;
+        // ---- explicit V panel (jb x len): unit diagonal, zeros to its left ----
+        for (int e = tid; e < jb * len; e += TTN_WG) {
+            const int jj = e / len, c = e % len;         // c relative to j0
+            double v;
+            if (c < jj) v = 0.0; else if (c == jj) v = 1.0; else v = M2[(long long)(j0 + jj) * ld + j0 + c];
+            Vb[(long long)jj * len + c] = v;
+        }
+        __syncthreads();
+        View Vv = mkview(Vb, plain(len), plain(1));                       // jb x len
+        // S = V V^T  (jb x jb)
+        wg_gemm(jb, jb, len, Vv, tview(Vv), mkview(Ss, plain(QR_NB), plain(1)), 1.0, 0.0, lds_gemm);
+        // T (upper triangular): T[j][j] = tau_j ; T[0:j, j] = -tau_j * T[0:j,0:j] * S[0:j, j]
+        if (tid == 0) {
+            for (int a = 0; a < jb * QR_NB; ++a) Ts[a] = 0.0;
+            for (int j = 0; j < jb; ++j) {
+                Ts[j * QR_NB + j] = taus[j];
+                for (int i = 0; i < j; ++i) {
+                    double acc = 0.0;
+                    for (int l = i; l < j; ++l) acc = fma(Ts[i * QR_NB + l], Ss[l * QR_NB + j], acc);
+                    Ts[i * QR_NB + j] = -taus[j] * acc;
+                }
+            }
+        }
+        __syncthreads();
+        // W = C V^T (rows_t x jb), C = M2[j0+jb:, j0:]
+        View Cv = mkview(M2 + (long long)(j0 + jb) * ld + j0, plain(ld), plain(1));
+        View Wv = mkview(Wb, plain(QR_NB), plain(1));
+        wg_gemm(rows_t, jb, len, Cv, tview(Vv), Wv, 1.0, 0.0, lds_gemm);
+        // W <- W T   (each thread one row)
+        for (int i = tid; i < rows_t; i += TTN_WG) {
+            double w[QR_NB], o[QR_NB];
+            for (int l = 0; l < jb; ++l) w[l] = Wb[(long long)i * QR_NB + l];
+            for (int c = 0; c < jb; ++c) {
+                double acc = 0.0;
+                for (int l = 0; l <= c; ++l) acc = fma(w[l], Ts[l * QR_NB + c], acc);
+                o[c] = acc;
+            }
+            for (int c = 0; c < jb; ++c) Wb[(long long)i * QR_NB + c] = o[c];
+        }
+        __syncthreads();
+        // C <- C - W V
+        wg_gemm(rows_t, len, jb, Wv, Vv, Cv, -1.0, 1.0, lds_gemm);
+    }
+    __syncthreads();
+}
+
+// -------------------------------------------------------------------------------------------------
+// One-sided (Hestenes) Jacobi on the columns of X (m x p, column-major, leading dimension ldx):
+// X <- X*W with orthogonal columns; on exit column i = sigma_i * u_i.  Round-robin parallel
+// ordering, one wave per column pair, lanes over rows.  Returns the number of sweeps used
+// (negative if the sweep limit was hit).  X may live in LDS or in global memory.
+// -------------------------------------------------------------------------------------------------
+__device__ __noinline__ int wg_jacobi_cols(int m, int p, double* X, int ldx, int* flag /*LDS*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    if (p < 2) return 0;
+    const int pe = p + (p & 1);               // even number of slots; slot p (if odd) is a bye
+    const int half = pe >> 1;
+    const double tol = sqrt((double)m) * DBL_EPSILON;
+    int sweep = 0;
+    for (; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        int rotated = 0;
+        for (int round = 0; round < pe - 1; ++round) {
+            for (int kk = wave; kk < half; kk += nwaves) {
+                int i, j;
+                if (kk == 0) { i = round; j = pe - 1; }
+                else { i = (round + kk) % (pe - 1); j = (round + pe - 1 - kk) % (pe - 1); }
+                if (i > j) { const int t = i; i = j; j = t; }
+                if (j >= p) continue;          // bye
+                double* xi = X + (long long)i * ldx;
+                double* xj = X + (long long)j * ldx;
+                double a = 0.0, b = 0.0, g = 0.0;
+                for (int r = lane; r < m; r += 64) {
+                    const double u = xi[r], v = xj[r];
+                    a = fma(u, u, a); b = fma(v, v, b); g = fma(u, v, g);
+                }
+                a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
+                if (a == 0.0 || b == 0.0) continue;
+                if (fabs(g) <= tol * sqrt(a) * sqrt(b)) continue;
+                // rotation annihilating g (Rutishauser formulas)
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+                const double cs = 1.0 / sqrt(fma(t, t, 1.0));
+                const double sn = cs * t;
+                for (int r = lane; r < m; r += 64) {
+                    const double u = xi[r], v = xj[r];
+                    xi[r] = cs * u - sn * v;
+                    xj[r] = sn * u + cs * v;
+                }
+                rotated = 1;
+            }
+            __syncthreads();
+        }
+        if (rotated && lane == 0) atomicOr(flag, 1);
+        __syncthreads();
+        const int any = *flag;
+        __syncthreads();
+        if (!any) return sweep + 1;
+    }
+    return -sweep;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Parameters of the compress / bond-truncate kernel
+// -------------------------------------------------------------------------------------------------
+struct CompressArgs {
+    TTDev tt;
+    long long max_bond;
+    double truncerr;
+    int sweeps;
+    int k_single;          // 0: full tt_compress! sweeps; else 1-based bond for _tt_bond_truncate!
+    double* scratch;       // per-train global scratch
+    long long scratch_stride;
+    int pmax, qmax;        // bounds on the short / long side of any merged matrix
+    double* sv_out;        // [batch][sv_steps][pmax] or null
+    int sv_steps;
+    int* status;           // [batch] device: 0 ok, 1 = Jacobi did not converge
+    int* sweep_stats;      // [batch] device: total Jacobi sweeps (diagnostics)
+};
+
+#define COMPRESS_LDS_X_DOUBLES (128 * 128)
+#define COMPRESS_LDS_BYTES ((COMPRESS_LDS_X_DOUBLES + 32 + 2 * QR_NB * QR_NB + QR_NB + 8 + 8) * sizeof(double))
+
+// One bond step on (core_k, core_{k+1}), 0-based k.  src/tt_tools.jl:743-768 with the effective
+// _svdtrunc of src/tt_cross_interpolation.jl:149-166.
+__device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, double* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    const TTDev& T = P.tt;
+    long long* rks = T.rks + (long long)b * (T.d + 1);
+    const int n1 = T.dims[k], n2 = T.dims[k + 1];
+    const int Dl = (int)rks[k], rm = (int)rks[k + 1], Dr = (int)rks[k + 2];
+    const int mr = n1 * Dl, mc = n2 * Dr;
+    double* ck = T.data + (long long)b * T.stride + T.off[k];
+    double* ck1 = T.data + (long long)b * T.stride + T.off[k + 1];
+    // A_mat[(al + Dl*s1), ga] = core_k[s1, al, ga] ; B_mat[ga, (s2 + n2*be)] = core_{k+1}[s2, ga, be]
+    const View Am = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));
+    const View Bm = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * rm});
+    const bool wide = mr <= mc;
+    const int p = wide ? mr : mc, q = wide ? mc : mr;
+    const View Ap = wide ? Am : tview(Bm);       // p x rm
+    const View Bp = wide ? Bm : tview(Am);       // rm x q
+
+    // ---- LDS carve-up ----
+    double* ldsX = lds;                                   // COMPRESS_LDS_X_DOUBLES (aliases the GEMM tiles)
+    double* red = lds + COMPRESS_LDS_X_DOUBLES;           // 32
+    double* Ts = red + 32;                                // QR_NB*QR_NB
+    double* Ss = Ts + QR_NB * QR_NB;                      // QR_NB*QR_NB
+    double* taus = Ss + QR_NB * QR_NB;                    // QR_NB
+    double* scal = taus + QR_NB;                          // 8 misc doubles
+    int* iflag = reinterpret_cast<int*>(scal + 8);        // 8 ints
+    // ---- global scratch carve-up ----
+    double* scr = P.scratch + (long long)b * P.scratch_stride;
+    const long long pq = (long long)P.pmax * P.qmax;
+    double* M = scr;                                      // p x q row-major
+    double* M2 = M + pq;                                  // copy for LQ
+    double* Vb = M2 + pq;                                 // QR_NB x qmax
+    double* Wb = Vb + (long long)QR_NB * P.qmax;          // pmax x QR_NB
+    double* Us = Wb + (long long)P.pmax * QR_NB;          // pmax x pmax (scaled, sorted left vectors)
+    double* Xg = Us + (long long)P.pmax * P.pmax;         // pmax x pmax Jacobi fallback when LDS is too small
+    double* sig = Xg + (long long)P.pmax * P.pmax;        // pmax singular values (unsorted)
+    double* sigs = sig + P.pmax;                          // pmax sorted
+    int* perm = reinterpret_cast<int*>(sigs + P.pmax);    // pmax ints: sorted position -> column
+
+    // ---- 1. merge: M = A' * B'  (p x q) ----
+    const View Mv = mkview(M, plain(q), plain(1));
+    wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds);
+
+    // ---- 2. scale to max|M| = 1 (guards the squared norms in Jacobi against over/underflow) ----
+    double mx = 0.0;
+    for (long long e = tid; e < (long long)p * q; e += TTN_WG) mx = fmax(mx, fabs(M[e]));
+    mx = wg_max(mx, red);
+    const double s0 = (mx > 0.0) ? mx : 1.0;
+    const double inv_s0 = 1.0 / s0;
+    const bool need_lq = q > p;
+    for (long long e = tid; e < (long long)p * q; e += TTN_WG) {
+        const double v = M[e] * inv_s0;
+        M[e] = v;
+        if (need_lq) M2[e] = v;
+    }
+    __syncthreads();
+
+    // ---- 3. triangular factor: L (p x p) with M = L Q ----
+    if (need_lq) wg_lq_factor(p, q, M2, q, Vb, Wb, lds, Ts, Ss, taus, red);
+
+    // ---- 4. Jacobi on the columns of L (or of M itself when square) ----
+    const bool x_in_lds = (long long)p * p <= COMPRESS_LDS_X_DOUBLES;
+    double* X = x_in_lds ? ldsX : Xg;
+    const double* Lsrc = need_lq ? M2 : M;               // row-major, ld = q
+    for (int e = tid; e < p * p; e += TTN_WG) {
+        const int r = e % p, c = e / p;                   // X[r + p*c] = L[r][c]
+        const double v = Lsrc[(long long)r * q + c];
+        X[e] = (need_lq && c > r) ? 0.0 : v;
+    }
+    __syncthreads();
+    const int nsw = wg_jacobi_cols(p, p, X, p, iflag);
+    if (tid == 0) {
+        if (nsw < 0) P.status[b] = 1;
+        P.sweep_stats[b] += (nsw < 0 ? -nsw : nsw);
+    }
+
+    // ---- 5. singular values, sort (descending, stable), rank rule ----
+    for (int c = wave; c < p; c += nwaves) {
+        double a = 0.0;
+        for (int r = lane; r < p; r += 64) { const double v = X[(long long)c * p + r]; a = fma(v, v, a); }
+        a = wave_sum(a);
+        if (lane == 0) sig[c] = sqrt(a);
+    }
+    __syncthreads();
+    for (int c = tid; c < p; c += TTN_WG) {
+        const double sc = sig[c];
+        int pos = 0;
+        for (int j = 0; j < p; ++j) { const double sj = sig[j]; pos += (sj > sc) || (sj == sc && j < c); }
+        perm[pos] = c;
+        sigs[pos] = sc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int r = p;
+        if (P.truncerr > 0.0) {
+            double nrm2 = 0.0;
+            for (int i = 0; i < p; ++i) { const double s = sigs[i] * s0; nrm2 = fma(s, s, nrm2); }
+            const double nrm = sqrt(nrm2);
+            double cum = 0.0;
+            for (int i = p; i >= 1; --i) {
+                const double s = sigs[i - 1] * s0;
+                cum = fma(s, s, cum);
+                if (sqrt(cum) > P.truncerr * nrm) { r = i; break; }
+            }
+        }
+        if ((long long)r > P.max_bond) r = (int)P.max_bond;
+        iflag[1] = r;
+    }
+    __syncthreads();
+    const int r = iflag[1];
+    if (P.sv_out && step < P.sv_steps) {
+        double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
+        for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? sigs[i] * s0 : -1.0;
+    }
+
+    // ---- 6. outputs.  left factor (p x r): x_j * sqrt(s0)/sqrt(sig_j) ; right factor (r x q):
+    //         (x_j^T M_scaled) * sqrt(s0) / (sig_j*sqrt(sig_j)) ----
+    const View Lfv = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));     // (mr x r)
+    const View Rfv = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * r});                 // (r x mc)
+    const View Lo = wide ? Lfv : tview(Rfv);       // p x r
+    const View Ro = wide ? Rfv : tview(Lfv);       // r x q
+    const double sq0 = sqrt(s0);
+    for (int e = tid; e < p * r; e += TTN_WG) {
+        const int row = e % p, j = e / p;
+        const double sj = sigs[j];
+        const double xv = X[(long long)perm[j] * p + row];
+        const double lf = (sj > 0.0) ? xv * (sq0 / sqrt(sj)) : 0.0;
+        const double us = (sj > 0.0) ? xv * (sq0 / (sj * sqrt(sj))) : 0.0;
+        Lo.p[ix(Lo.r, row) + ix(Lo.c, j)] = lf;
+        Us[(long long)j * p + row] = us;            // Us^T stored: (r x p) row-major
+    }
+    __syncthreads();
+    wg_gemm(r, q, p, mkview(Us, plain(p), plain(1)), Mv, Ro, 1.0, 0.0, lds);
+    if (tid == 0) rks[k + 1] = r;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {
+    extern __shared__ double lds[];
+    const int b = blockIdx.x;
+    const int d = P.tt.d;
+    if (threadIdx.x == 0) { P.status[b] = 0; P.sweep_stats[b] = 0; }
+    __syncthreads();
+    int step = 0;
+    if (P.k_single > 0) {
+        wg_bond_step(P, b, P.k_single - 1, step, lds);
+        return;
+    }
+    for (int sw = 0; sw < P.sweeps; ++sw) {
+        for (int k = 0; k < d - 1; ++k) wg_bond_step(P, b, k, step++, lds);
+        for (int k = d - 2; k >= 0; --k) wg_bond_step(P, b, k, step++, lds);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// dot: transfer-matrix recurrence (src/tt_operations.jl:239-250), one workgroup per train pair.
+//   T[al, (z,b)] = sum_be M[al,be] * B[z,be,b]        (ra x rb) * (rb x n*rb')
+//   M'[a, b]     = sum_{(z,al)} A[z,al,a] * T[(z,al), b]
+// -------------------------------------------------------------------------------------------------
+struct DotArgs {
+    TTDev a, b;
+    double* scratch;            // per train: 2 * ramax*rbmax + nmax*ramax*rbmax
+    long long scratch_stride;
+    int ramax, rbmax, nmax;
+    double* out;                // [batch] device
+};
+
+__global__ void __launch_bounds__(TTN_WG) k_dot(DotArgs P) {
+    extern __shared__ double lds[];
+    const int t = blockIdx.x;
+    const TTDev& A = P.a; const TTDev& B = P.b;
+    const long long* ar = A.rks + (long long)t * (A.d + 1);
+    const long long* br = B.rks + (long long)t * (B.d + 1);
+    double* scr = P.scratch + (long long)t * P.scratch_stride;
+    double* M0 = scr;
+    double* M1 = M0 + (long long)P.ramax * P.rbmax;
+    double* Tb = M1 + (long long)P.ramax * P.rbmax;
+    if (threadIdx.x == 0) M0[0] = 1.0;
+    __syncthreads();
+    double* Mc = M0; double* Mn = M1;
+    for (int k = 0; k < A.d; ++k) {
+        const int n = A.dims[k];
+        const int ra = (int)ar[k], ra2 = (int)ar[k + 1], rb = (int)br[k], rb2 = (int)br[k + 1];
+        double* Ak = A.data + (long long)t * A.stride + A.off[k];
+        double* Bk = B.data + (long long)t * B.stride + B.off[k];
+        // M (ra x rb) column-major: M[al + ra*be]
+        const View Mv = mkview(Mc, plain(1), plain(ra));
+        // B as [be, (z + n*b)] : offset z + n*be + n*rb*b
+        const View Bv = mkview(Bk, plain(n), Idx{n, 1, (long long)n * rb});
+        // T as [al, (z + n*b)] stored at z + n*al + n*ra*b  (so that (z,al) is a plain K index below)
+        const View Tv = mkview(Tb, plain(n), Idx{n, 1, (long long)n * ra});
+        wg_gemm(ra, n * rb2, rb, Mv, Bv, Tv, 1.0, 0.0, lds);
+        // A^T as [a, (z + n*al)] : offset (z + n*al) + n*ra*a ; T as [(z + n*al), b] : offset kk + n*ra*b
+        const View Atv = mkview(Ak, plain((long long)n * ra), plain(1));
+        const View T2v = mkview(Tb, plain(1), plain((long long)n * ra));
+        const View Mnv = mkview(Mn, plain(1), plain(ra2));
+        wg_gemm(ra2, rb2, n * ra, Atv, T2v, Mnv, 1.0, 0.0, lds);
+        double* tmp = Mc; Mc = Mn; Mn = tmp;
+    }
+    if (threadIdx.x == 0) P.out[t] = Mc[0];
+}

@@ -1,0 +1,179 @@
+// ttn_stream_kernels.h — HBM-bound per-core kernels: apply (tto*ttv), hadamard, +, scalar*.
+// Every kernel is launched on grid (tiles, d, batch): blockIdx.y = core, blockIdx.z = train.
+// Ranks are read from device memory (they are data dependent after tt_compress!).
+#pragma once
+#include "ttn_common.h"
+
+#define TTN_STREAM_TB 256
+
+// ---------------------------------------------------------------------------------------------
+// rank bookkeeping (Int64, bit-exact): tiny one-block kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_ranks_mul_op(TTDev y, TTODev A, TTDev x) {      // y.rks = A.rks .* x.rks  (tt_operations.jl:103)
+    int b = blockIdx.x;
+    for (int m = threadIdx.x; m <= x.d; m += blockDim.x)
+        y.rks[(long long)b * (y.d + 1) + m] = A.rks[m] * x.rks[(long long)b * (x.d + 1) + m];
+}
+__global__ void k_ranks_mul(TTDev z, TTDev x, TTDev y) {          // hadamard: ranks multiply (tt_operations.jl:348)
+    int b = blockIdx.x;
+    for (int m = threadIdx.x; m <= x.d; m += blockDim.x)
+        z.rks[(long long)b * (z.d + 1) + m] = x.rks[(long long)b * (x.d + 1) + m] * y.rks[(long long)b * (y.d + 1) + m];
+}
+__global__ void k_ranks_add(TTDev z, TTDev x, TTDev y) {          // +: ranks add, ends forced to 1 (tt_operations.jl:14-16)
+    int b = blockIdx.x;
+    for (int m = threadIdx.x; m <= x.d; m += blockDim.x) {
+        long long r = x.rks[(long long)b * (x.d + 1) + m] + y.rks[(long long)b * (y.d + 1) + m];
+        if (m == 0 || m == x.d) r = 1;
+        z.rks[(long long)b * (z.d + 1) + m] = r;
+    }
+}
+__global__ void k_ranks_copy(TTDev y, TTDev x) {
+    int b = blockIdx.x;
+    for (int m = threadIdx.x; m <= x.d; m += blockDim.x)
+        y.rks[(long long)b * (y.d + 1) + m] = x.rks[(long long)b * (x.d + 1) + m];
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply:  Y_k[i, a' + Rl*v', a + Rr*v] = sum_j A_k[i,j,a',a] * X_k[j,v',v]
+// (src/tt_operations.jl:101-111; operator index fastest in the combined rank index, from the
+// reshape at :106).  One thread per (p,q) output column: reads n doubles of X, writes n doubles
+// of Y (16 B for n=2) with consecutive threads on consecutive p -> coalesced stores; the operator
+// core (n*n*Rl*Rr doubles, 36 for the Laplacian) is staged in LDS.  HBM-write bound.
+// ---------------------------------------------------------------------------------------------
+#define TTN_APPLY_LDS_DOUBLES 4096
+__global__ void __launch_bounds__(TTN_STREAM_TB) k_apply(TTODev A, TTDev x, TTDev y) {
+    __shared__ double As[TTN_APPLY_LDS_DOUBLES];
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int n = x.dims[k];
+    const int Rl = (int)A.rks[k], Rr = (int)A.rks[k + 1];
+    const long long* xr = x.rks + (long long)b * (x.d + 1);
+    const int rl = (int)xr[k], rr = (int)xr[k + 1];
+    const int P = Rl * rl, Q = Rr * rr;
+    const long long total = (long long)P * Q;
+    const long long first = (long long)blockIdx.x * blockDim.x;
+    if (first >= total) return;
+    const double* Ak = A.data + A.off[k];
+    const int asz = n * n * Rl * Rr;
+    const bool in_lds = asz <= TTN_APPLY_LDS_DOUBLES;
+    if (in_lds) {
+        for (int e = threadIdx.x; e < asz; e += blockDim.x) As[e] = Ak[e];
+        __syncthreads();
+    }
+    const double* Ap = in_lds ? As : Ak;
+    const double* Xk = x.data + (long long)b * x.stride + x.off[k];
+    double* Yk = y.data + (long long)b * y.stride + y.off[k];
+    for (long long e = first + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(e % P), q = (int)(e / P);
+        const int al = p % Rl, vl = p / Rl;       // a', v'
+        const int ar = q % Rr, vr = q / Rr;       // a , v
+        const double* xs = Xk + (long long)n * (vl + (long long)rl * vr);
+        const double* ap = Ap + (long long)n * n * (al + (long long)Rl * ar);
+        double* yo = Yk + (long long)n * e;
+        if (n == 2) {
+            const double x0 = xs[0], x1 = xs[1];
+            double2 o;
+            o.x = fma(ap[2], x1, ap[0] * x0);     // i=0: A[0,0]*x0 + A[0,1]*x1
+            o.y = fma(ap[3], x1, ap[1] * x0);     // i=1
+            *reinterpret_cast<double2*>(yo) = o;
+        } else {
+            for (int i = 0; i < n; ++i) {
+                double acc = ap[i] * xs[0];
+                for (int j = 1; j < n; ++j) acc = fma(ap[i + n * j], xs[j], acc);
+                yo[i] = acc;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hadamard: Z_k[s, ay + ryl*ax, by + ryr*bx] = X_k[s,ax,bx] * Y_k[s,ay,by]
+// (src/tt_operations.jl:343-361: kron per physical slice, y index fastest)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TTN_STREAM_TB) k_hadamard(TTDev x, TTDev y, TTDev z) {
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int n = x.dims[k];
+    const long long* xr = x.rks + (long long)b * (x.d + 1);
+    const long long* yr = y.rks + (long long)b * (y.d + 1);
+    const int rxl = (int)xr[k], rxr = (int)xr[k + 1], ryl = (int)yr[k], ryr = (int)yr[k + 1];
+    const int P = rxl * ryl, Q = rxr * ryr;
+    const long long total = (long long)P * Q;
+    const double* Xk = x.data + (long long)b * x.stride + x.off[k];
+    const double* Yk = y.data + (long long)b * y.stride + y.off[k];
+    double* Zk = z.data + (long long)b * z.stride + z.off[k];
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(e % P), q = (int)(e / P);
+        const int ay = p % ryl, ax = p / ryl, by = q % ryr, bx = q / ryr;
+        const double* xs = Xk + (long long)n * (ax + (long long)rxl * bx);
+        const double* ys = Yk + (long long)n * (ay + (long long)ryl * by);
+        double* zo = Zk + (long long)n * e;
+        if (n == 2) {
+            double2 o;
+            o.x = xs[0] * ys[0];
+            o.y = xs[1] * ys[1];
+            *reinterpret_cast<double2*>(zo) = o;
+        } else {
+            for (int s = 0; s < n; ++s) zo[s] = xs[s] * ys[s];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// +: block concat (src/tt_operations.jl:10-35).  first core [X Y], middle diag(X,Y), last [X;Y].
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TTN_STREAM_TB) k_add(TTDev x, TTDev y, TTDev z) {
+    const int k = blockIdx.y, b = blockIdx.z, d = x.d;
+    const int n = x.dims[k];
+    const long long* xr = x.rks + (long long)b * (d + 1);
+    const long long* yr = y.rks + (long long)b * (d + 1);
+    const int rxl = (int)xr[k], rxr = (int)xr[k + 1], ryl = (int)yr[k], ryr = (int)yr[k + 1];
+    const int zl = (k == 0) ? 1 : rxl + ryl, zr = (k == d - 1) ? 1 : rxr + ryr;
+    const long long total = (long long)zl * zr;
+    const double* Xk = x.data + (long long)b * x.stride + x.off[k];
+    const double* Yk = y.data + (long long)b * y.stride + y.off[k];
+    double* Zk = z.data + (long long)b * z.stride + z.off[k];
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int a = (int)(e % zl), c = (int)(e / zl);
+        const double* src = nullptr;
+        // row block: first core has the single row shared by X and Y; column block likewise at the end
+        const bool ax = (k == 0) ? true : (a < rxl);
+        const bool cx = (k == d - 1) ? true : (c < rxr);
+        const bool ay = (k == 0) ? true : (a >= rxl);
+        const bool cy = (k == d - 1) ? true : (c >= rxr);
+        if (k == 0) {
+            src = (c < rxr) ? Xk + (long long)n * (0 + (long long)rxl * c) : Yk + (long long)n * (0 + (long long)ryl * (c - rxr));
+        } else if (k == d - 1) {
+            src = (a < rxl) ? Xk + (long long)n * (a + (long long)rxl * 0) : Yk + (long long)n * ((a - rxl) + (long long)ryl * 0);
+        } else if (ax && cx) {
+            src = Xk + (long long)n * (a + (long long)rxl * c);
+        } else if (ay && cy) {
+            src = Yk + (long long)n * ((a - rxl) + (long long)ryl * (c - rxr));
+        }
+        double* zo = Zk + (long long)n * e;
+        for (int s = 0; s < n; ++s) zo[s] = src ? src[s] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar *: copy every core, scale core `which` by a (src/tt_operations.jl:256-266); zero==1 -> all-zero train
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TTN_STREAM_TB) k_scale(TTDev x, TTDev y, double a, int which, int zero) {
+    const int k = blockIdx.y, b = blockIdx.z;
+    const long long* xr = x.rks + (long long)b * (x.d + 1);
+    const long long total = (long long)x.dims[k] * xr[k] * xr[k + 1];
+    const double* Xk = x.data + (long long)b * x.stride + x.off[k];
+    double* Yk = y.data + (long long)b * y.stride + y.off[k];
+    const double f = (k == which) ? a : 1.0;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+        Yk[e] = zero ? 0.0 : ((k == which) ? f * Xk[e] : Xk[e]);
+}
+
+// replicate train src over the whole batch (cores + ranks)
+__global__ void __launch_bounds__(TTN_STREAM_TB) k_replicate(TTDev x, int src) {
+    const int b = blockIdx.y;
+    if (b == src) return;
+    const double* s = x.data + (long long)src * x.stride;
+    double* t = x.data + (long long)b * x.stride;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < x.stride; e += (long long)gridDim.x * blockDim.x) t[e] = s[e];
+    if (blockIdx.x == 0)
+        for (int m = threadIdx.x; m <= x.d; m += blockDim.x) x.rks[(long long)b * (x.d + 1) + m] = x.rks[(long long)src * (x.d + 1) + m];
+}

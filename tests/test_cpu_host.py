@@ -1,0 +1,144 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol of include/ttn.h,
+the product-side input generators agree bit-for-bit with the oracle's restatement of the reference
+constructors, the golden fixtures are consistent with the oracle, and host-side argument checks raise
+the reference's exception types before anything touches a device."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import tt_oracle as O
+from tests.helpers import load_golden, tt_from_golden, tto_from_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def T():
+    import __graft_entry__ as g
+    g.build()
+    import ttn_amd
+    return ttn_amd
+
+
+def test_library_exports_every_declared_symbol(T):
+    hdr = open(os.path.join(ROOT, "include", "ttn.h")).read()
+    declared = set(re.findall(r"\b(ttn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(T._lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"libttn_hip.so does not export: {missing}"
+    assert declared == set(T._lib.SIGNATURES), "ctypes signature table out of sync with ttn.h"
+    assert b"gfx950" in T._lib.lib().ttn_version()
+
+
+def test_library_contains_gfx950_code_object(T):
+    blob = open(T._lib.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+    for k in (b"k_apply", b"k_compress", b"k_dot", b"k_hadamard", b"k_orthogonalize"):
+        assert k in blob
+
+
+def test_r_and_d_to_rks_matches_oracle_and_reference_vectors(T):
+    assert T.r_and_d_to_rks([5, 5, 5], (0, 2), rmax=4) == [1, 2, 1]          # test/test_tt_tools.jl:945
+    assert T.r_and_d_to_rks([5, 5, 5], (0, 0), rmax=4) == [1, 4, 1]          # :946
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        d = int(rng.integers(1, 9))
+        dims = [int(v) for v in rng.integers(0, 5, size=d)]
+        rks = [int(v) for v in rng.integers(1, 40, size=d + 1)]
+        rmax = int(rng.integers(1, 50))
+        assert T.r_and_d_to_rks(rks, dims, rmax=rmax) == O.r_and_d_to_rks(rks, dims, rmax=rmax)
+    # Julia's Int64 products wrap: 64 sites of dimension 2 give prod = 2^64 = 0
+    dims = [2] * 64
+    out = T.r_and_d_to_rks([7] * 65, dims, rmax=1024)
+    assert out[0] == 1 and out[1] == 2 and out[-1] == 1
+
+
+def _same_tt(a, b):
+    assert list(a.ttv_rks) == list(b.ttv_rks) and tuple(a.ttv_dims) == tuple(b.ttv_dims)
+    for ca, cb in zip(a.ttv_vec, b.ttv_vec):
+        assert np.array_equal(np.asarray(ca), np.asarray(cb))
+
+
+def test_constructors_bit_exact_vs_oracle(T):
+    for d in (2, 3, 6, 12, 30):
+        A, B = T.Delta(d), O.Delta(d)
+        assert A.tto_rks == B.tto_rks
+        for ca, cb in zip(A.tto_vec, B.tto_vec):
+            assert np.array_equal(ca, cb)
+        for ca, cb in zip(T.toeplitz_to_qtto(0.5, 3.0, -7.0, d).tto_vec, O.toeplitz_to_qtto(0.5, 3.0, -7.0, d).tto_vec):
+            assert np.array_equal(ca, cb)
+        for ca, cb in zip(T.id_tto(d).tto_vec, O.id_tto(d).tto_vec):
+            assert np.array_equal(ca, cb)
+        if d >= 3:
+            _same_tt(T.qtt_sin(d, lam=math.pi), O.qtt_sin(d, lam=math.pi))
+            _same_tt(T.qtt_cos(d, a=0.1, b=2.0, lam=0.3), O.qtt_cos(d, a=0.1, b=2.0, lam=0.3))
+            _same_tt(T.qtt_exp(d, alpha=-1.5, beta=0.2), O.qtt_exp(d, alpha=-1.5, beta=0.2))
+    v = T.qtt_sin(8, lam=math.pi)
+    assert np.allclose(T.qtt_to_vector(v), O.qtt_to_vector(O.qtt_sin(8, lam=math.pi)), rtol=0, atol=1e-15)
+
+
+def test_rand_tt_profile_and_determinism(T):
+    x = T.rand_tt((2,) * 30, 64, seed=30)
+    assert x.ttv_rks == [1, 2, 4, 8, 16, 32] + [64] * 19 + [32, 16, 8, 4, 2, 1]
+    y = T.rand_tt((2,) * 30, 64, seed=30)
+    assert all(np.array_equal(a, b) for a, b in zip(x.ttv_vec, y.ttv_vec))
+    z = T.portable_randn(200000, 7)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    assert all(c.flags["F_CONTIGUOUS"] for c in x.ttv_vec)
+
+
+def test_golden_fixtures_consistent_with_oracle():
+    g = load_golden("closed_forms.npz")
+    for d in (4, 6):
+        n = 2 ** d
+        assert np.array_equal(g[f"delta{d}_dense"], 2 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1))
+        for k, c in enumerate(O.Delta(d).tto_vec):
+            assert np.array_equal(g[f"delta{d}_core{k}"], c)
+    x = np.linspace(0, 1, 64)
+    assert np.allclose(g["sin6_dense"], np.sin(math.pi ** 2 * x), atol=1e-12)
+    assert np.allclose(g["c1_dense"], np.sin(math.pi ** 2 * x), atol=1e-12)
+    assert list(g["c1_compressed_rks"]) == [1, 2, 2, 2, 2, 2, 1]
+    r = load_golden("random_small.npz")
+    for name in "abce":
+        xs, ys, A = tt_from_golden(r, f"{name}_x"), tt_from_golden(r, f"{name}_y"), tto_from_golden(r, f"{name}_A")
+        assert math.isclose(float(r[f"{name}_dot"]), O.dot(xs, ys), rel_tol=1e-13)
+        ax = O.apply(A, xs)
+        assert list(r[f"{name}_apply_rks"]) == ax.ttv_rks
+        z = O.copy_tt(ax)
+        O.tt_compress_(z, int(r[f"{name}_max_bond"]), truncerr=float(r[f"{name}_truncerr"]))
+        assert list(r[f"{name}_compress_rks"]) == z.ttv_rks
+        assert np.allclose(r[f"{name}_compress_dense"], O.ttv_to_tensor(z), atol=1e-12)
+
+
+def test_host_side_assertions_need_no_device(T):
+    x = T.rand_tt((2, 2, 2), [1, 2, 2, 1], seed=1)
+    with pytest.raises(AssertionError, match="sweeps must be >= 1"):
+        T.tt_compress_(x, 2, sweeps=0)                      # test/test_tt_tools.jl:548
+    with pytest.raises(AssertionError, match=r"k must be in 1:\(N-1\)"):
+        T._tt_bond_truncate_(x, 0)                          # :495
+    with pytest.raises(AssertionError):
+        T._tt_bond_truncate_(x, x.N)                        # :496
+    with pytest.raises(AssertionError, match="Impossible orthogonalization"):
+        T.orthogonalize(x, i=4)
+    y = T.rand_tt((2, 3, 2), [1, 2, 2, 1], seed=2)
+    with pytest.raises(AssertionError, match="Incompatible dimensions"):
+        T.add(x, y)
+    with pytest.raises(AssertionError):
+        T.dot(x, y)
+    with pytest.raises(AssertionError):
+        T.hadamard(x, y)
+    with pytest.raises(AssertionError):
+        T.apply(T.Delta(4), x)
+
+
+def test_c_abi_argument_errors_without_gpu(T):
+    L = T._lib.lib()
+    assert L.ttn_sync() == T._lib.TTN_ERR_NOT_INIT or L.ttn_sync() == 0
+    out = (ctypes.c_int64 * 3)()
+    assert L.ttn_r_and_d_to_rks(2, None, 3, None, 4, out) == T._lib.TTN_ERR_ARG
+    assert b"bad argument" in L.ttn_last_error_string()

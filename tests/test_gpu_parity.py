@@ -1,0 +1,406 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/ttn.h) against the CPU oracle and
+the committed golden fixtures.  Tolerances (fp64):
+  layout / ranks / ot flags / rank decisions ........ bit-exact
+  apply, hadamard, +, scalar* ....................... bit-exact for {0,±1,2}-valued operators and pure
+                                                      copies/products; rtol 4 ulp for general operators
+  dot / norm ........................................ rtol 1e-12
+  orthogonalize ..................................... reconstruction 1e-12 rel, ||QᵀQ − I||_max 1e-12
+  tt_compress! ...................................... singular values rtol 1e-10 (atol 1e-13·σ₁),
+                                                      ||y_gpu − y_cpu|| / ||y_cpu|| ≤ 1e-9
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import tt_oracle as O
+from tests.helpers import (load_golden, sign_fix_compare, to_oracle, to_product, tt_from_golden, tt_rel_diff,
+                           tto_from_golden)
+
+pytestmark = pytest.mark.gpu
+
+ULP4 = 4 * np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def T():
+    import ttn_amd
+    ttn_amd.ensure_init(0)
+    return ttn_amd
+
+
+def _cores_equal(a, b, rtol=0.0):
+    assert list(a.ttv_rks) == list(b.ttv_rks)
+    assert list(a.ttv_ot) == list(b.ttv_ot)
+    for ca, cb in zip(a.ttv_vec, b.ttv_vec):
+        ca, cb = np.asarray(ca), np.asarray(cb)
+        assert ca.shape == cb.shape
+        if rtol == 0.0:
+            assert np.array_equal(ca, cb)
+        else:
+            assert np.allclose(ca, cb, rtol=rtol, atol=rtol * np.max(np.abs(cb)))
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list("abce"))
+def test_golden_random_small(T, name):
+    g = load_golden("random_small.npz")
+    x, y, A = tt_from_golden(g, f"{name}_x"), tt_from_golden(g, f"{name}_y"), tto_from_golden(g, f"{name}_A")
+    px, py, pA = to_product(x), to_product(y), to_product(A)
+    _cores_equal(T.apply(pA, px), tt_from_golden(g, f"{name}_apply"), rtol=ULP4)
+    _cores_equal(T.hadamard(px, py), tt_from_golden(g, f"{name}_hadamard"))
+    _cores_equal(T.add(px, py), tt_from_golden(g, f"{name}_add"))
+    _cores_equal(T.scale(-2.5, px), tt_from_golden(g, f"{name}_scale"))
+    assert math.isclose(T.dot(px, py), float(g[f"{name}_dot"]), rel_tol=1e-12)
+    assert math.isclose(T.norm(px), float(g[f"{name}_norm_x"]), rel_tol=1e-12)
+    dense = g[f"{name}_x_dense"]
+    for c in range(1, x.N + 1):
+        o = T.orthogonalize(px, i=c)
+        assert o.ttv_rks == list(g[f"{name}_orth{c}_rks"]) and o.ttv_ot == list(g[f"{name}_orth{c}_ot"])
+        assert np.allclose(O.ttv_to_tensor(to_oracle(o)), dense, atol=1e-12 * np.max(np.abs(dense)))
+    # apply + round with per-bond singular values
+    mb, te = int(g[f"{name}_max_bond"]), float(g[f"{name}_truncerr"])
+    dA = T.DeviceTTO(pA)
+    dx = T.DeviceTT.from_host(px)
+    dy = T.DeviceTT(px.ttv_dims, [a * b for a, b in zip(pA.tto_rks, px.ttv_rks)])
+    dy.capture_singular_values(True)
+    T.device.apply_compress(dA, dx, dy, mb, te, 1)
+    T.device.compress_status(dy)
+    z = dy.download()
+    assert z.ttv_rks == list(g[f"{name}_compress_rks"])
+    ref = g[f"{name}_compress_dense"]
+    assert np.allclose(O.ttv_to_tensor(to_oracle(z)), ref, atol=1e-10 * np.max(np.abs(ref)))
+    for i in range(int(g[f"{name}_compress_nsv"])):
+        sv_ref = g[f"{name}_compress_sv{i}"]
+        sv = dy.singular_values(0, i)
+        assert len(sv) >= len(sv_ref)
+        assert np.allclose(sv[: len(sv_ref)], sv_ref, rtol=1e-10, atol=1e-13 * sv_ref[0])
+
+
+def test_golden_config1(T):
+    """BASELINE.json config 1: tt_compress!(id_tto(6) * qtt_sin(6, λ=π), 2) — README.md:84-103 inputs."""
+    g = load_golden("closed_forms.npz")
+    y = T.id_tto(6) * T.qtt_sin(6, lam=math.pi)
+    _cores_equal(y, tt_from_golden(g, "c1_applied"))
+    r = T.tt_compress_(y, 2)
+    assert r is y and y.ttv_rks == [1, 2, 2, 2, 2, 2, 1]
+    assert np.allclose(T.qtt_to_vector(y), g["c1_dense"], atol=1e-12)
+    assert np.allclose(T.qtt_to_vector(y), np.sin(math.pi ** 2 * np.linspace(0, 1, 64)), atol=1e-12)
+    for k, c in enumerate(y.ttv_vec):
+        assert c.shape == (2, y.ttv_rks[k], y.ttv_rks[k + 1])
+
+
+# ------------------------------------------------------------------------------------------------
+# apply
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,r", [(4, 3), (12, 16), (20, 32)])
+def test_apply_laplacian_bit_exact(T, d, r):
+    x = T.rand_tt((2,) * d, r, seed=d)
+    got = T.Delta(d) * x
+    ref = O.apply(O.Delta(d), to_oracle(x))
+    _cores_equal(got, ref)                 # entries of Δ are in {0,±1,2}: products exact, one rounding per sum
+    assert got.ttv_rks == [a * b for a, b in zip(T.Delta(d).tto_rks, x.ttv_rks)] and got.ttv_ot == [0] * d
+
+
+def test_apply_general_dims_and_callable(T):
+    rng = np.random.default_rng(21)
+    dims = (2, 3, 4, 3)
+    A = O.rand_tto(dims, 3, rng)
+    v = O.rand_tt(dims, [1, 2, 4, 3, 1], rng)
+    pA, pv = to_product(A), to_product(v)
+    ref = O.apply(A, v)
+    _cores_equal(pA * pv, ref, rtol=ULP4)
+    _cores_equal(pA(pv), ref, rtol=ULP4)   # test/test_tt_operations.jl:116-122
+    TA = O.tto_to_tensor(A)
+    dense = np.einsum("abcdefgh,efgh->abcd", TA, O.ttv_to_tensor(v))
+    assert np.allclose(O.ttv_to_tensor(to_oracle(pA * pv)), dense, atol=1e-12)
+
+
+def test_apply_full_size_linearity(T):
+    """C3-sized property test: A(x + 2y) == A x + 2 A y as tensors (TT inner products)."""
+    d = 30
+    x = T.rand_tt((2,) * d, 16, seed=1)
+    y = T.rand_tt((2,) * d, 16, seed=2)
+    A = T.Delta(d)
+    lhs = A * (x + 2.0 * y)
+    rhs = (A * x) + 2.0 * (A * y)
+    assert T.euclidean_distance(lhs, rhs) <= 1e-12 * T.norm(rhs)
+
+
+# ------------------------------------------------------------------------------------------------
+# dot / norm / hadamard / + / scalar
+# ------------------------------------------------------------------------------------------------
+def test_dot_norm_closed_forms(T):
+    d = 8                                   # test/test_tt_operations.jl:303-320
+    A1, A2 = T.qtt_exp(d), T.qtt_sin(d, lam=math.pi)
+    S1, S2 = T.qtt_to_vector(A1), T.qtt_to_vector(A2)
+    assert T.euclidean_distance(A1, A1) == 0.0
+    assert math.isclose(T.dot(A1, A2), float(S1 @ S2), rel_tol=1e-10)
+    assert math.isclose(T.norm(A2), float(np.linalg.norm(S2)), rel_tol=1e-10)
+    assert abs(math.sqrt(S1 @ S1 - 2 * (S1 @ S2) + S2 @ S2) - T.euclidean_distance(A1, A2)) < 1e-10
+
+
+@pytest.mark.parametrize("d,ra,rb", [(20, 32, 96), (30, 64, 192)])
+def test_dot_full_size_vs_oracle(T, d, ra, rb):
+    a = T.rand_tt((2,) * d, ra, seed=5)
+    b = T.rand_tt((2,) * d, rb, seed=6)
+    ref = O.dot(to_oracle(a), to_oracle(b))
+    assert math.isclose(T.dot(a, b), ref, rel_tol=1e-12, abs_tol=1e-12 * O.norm(to_oracle(a)) * O.norm(to_oracle(b)))
+    assert math.isclose(T.norm(a), O.norm(to_oracle(a)), rel_tol=1e-12)
+
+
+def test_hadamard_closed_forms(T):
+    d = 8                                   # test/test_tt_operations.jl:41-71
+    x = np.linspace(0, 1, 2 ** d)
+    A1, A2, A3 = T.qtt_exp(d), T.qtt_sin(d, lam=math.pi), T.qtt_cos(d, lam=math.pi)
+    assert np.allclose(T.qtt_to_vector(T.hadamard(A2, A3)), np.cos(math.pi ** 2 * x) * np.sin(math.pi ** 2 * x), atol=1e-12, rtol=0)
+    assert np.allclose(T.qtt_to_vector(T.hadamard(A1, A2)), np.exp(x) * np.sin(math.pi ** 2 * x), atol=1e-12, rtol=0)
+    big = T.hadamard(T.rand_tt((2,) * 10, 8, seed=1), T.rand_tt((2,) * 10, 12, seed=2))
+    ref = O.hadamard(to_oracle(T.rand_tt((2,) * 10, 8, seed=1)), to_oracle(T.rand_tt((2,) * 10, 12, seed=2)))
+    _cores_equal(big, ref)
+
+
+def test_add_and_inplace_add(T):
+    rng = np.random.default_rng(1)          # test/test_tt_operations.jl:106-114
+    x = to_product(O.rand_tt((2, 3), [1, 2, 1], rng))
+    y = to_product(O.rand_tt((2, 3), [1, 3, 1], rng))
+    expected = O.ttv_to_tensor(to_oracle(x + y))
+    assert np.allclose(expected, O.ttv_to_tensor(to_oracle(x)) + O.ttv_to_tensor(to_oracle(y)), atol=1e-12)
+    r = T.add_(x, y)
+    assert r is x and x.ttv_rks == [1, 5, 1] and all(o == 0 for o in x.ttv_ot)
+    assert np.allclose(O.ttv_to_tensor(to_oracle(x)), expected, atol=1e-12)
+
+
+def test_scale_semantics(T):
+    x = T.rand_tt((2,) * 5, 3, seed=9)
+    x.ttv_ot = [1, 1, 0, -1, -1]
+    y = 3.0 * x
+    ref = O.scale(3.0, to_oracle(x))
+    _cores_equal(y, ref)                    # scales the first core with ot == 0 (site 3); ot copied
+    z = 0.0 * x
+    assert z.ttv_ot == [0] * 5 and all(np.all(c == 0) for c in z.ttv_vec) and z.ttv_rks == x.ttv_rks
+    w = x - x
+    assert T.norm(w) <= 1e-14 * T.norm(x)
+    _cores_equal(x / 4.0, O.div(to_oracle(x), 4.0))
+
+
+# ------------------------------------------------------------------------------------------------
+# orthogonalize
+# ------------------------------------------------------------------------------------------------
+def test_orthogonalize_reference_properties(T):
+    rng = np.random.default_rng(3)          # test/test_tt_tools.jl:981-1017
+    dims = (2, 3, 4)
+    tt = to_product(O.rand_tt(dims, [1, 2, 3, 1], rng))
+    T0 = O.ttv_to_tensor(to_oracle(tt))
+    for center in (1, 2, 3):
+        orth = T.orthogonalize(tt, i=center)
+        assert np.allclose(O.ttv_to_tensor(to_oracle(orth)), T0, atol=1e-12)
+        assert orth.ttv_ot[center - 1] == 0
+        assert all(orth.ttv_ot[j] == 1 for j in range(center - 1))
+        assert all(orth.ttv_ot[j] == -1 for j in range(center, 3))
+        for j in range(center - 1):
+            G = np.asarray(orth.ttv_vec[j])
+            n, rl, rr = G.shape
+            A = G.transpose(1, 0, 2).reshape(rl * n, rr, order="F")
+            assert np.allclose(A.T @ A, np.eye(rr), atol=1e-12)
+        for j in range(center, 3):
+            G = np.asarray(orth.ttv_vec[j])
+            n, rl, rr = G.shape
+            A = G.transpose(1, 2, 0).reshape(rl, rr * n, order="F")
+            assert np.allclose(A @ A.T, np.eye(rl), atol=1e-12)
+
+
+@pytest.mark.parametrize("d,r,center", [(12, 20, 1), (12, 20, 7), (12, 20, 12), (16, 48, 1)])
+def test_orthogonalize_vs_oracle(T, d, r, center):
+    x = T.Delta(d) * T.rand_tt((2,) * d, r // 3 + 1, seed=d + center)      # rank-deficient-ish input, ranks 3*(...)
+    got = T.orthogonalize(x, i=center)
+    ref = O.orthogonalize(to_oracle(x), i=center)
+    assert got.ttv_rks == ref.ttv_rks and got.ttv_ot == ref.ttv_ot
+    assert tt_rel_diff(to_oracle(got), to_oracle(x)) < 1e-12
+    for j, G in enumerate(got.ttv_vec):
+        G = np.asarray(G)
+        n, rl, rr = G.shape
+        if j < center - 1:
+            A = G.transpose(1, 0, 2).reshape(rl * n, rr, order="F")
+            assert np.max(np.abs(A.T @ A - np.eye(rr))) < 1e-12
+        elif j > center - 1:
+            A = G.transpose(1, 2, 0).reshape(rl, rr * n, order="F")
+            assert np.max(np.abs(A @ A.T - np.eye(rl))) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------
+# _tt_bond_truncate! / tt_compress!
+# ------------------------------------------------------------------------------------------------
+def test_bond_truncate_reference_cases(T):
+    rng = np.random.default_rng(5)          # test/test_tt_tools.jl:433-498
+    tt = T.TTvector(3, [rng.standard_normal((2, 1, 4)), rng.standard_normal((2, 4, 4)), rng.standard_normal((2, 4, 1))],
+                    (2, 2, 2), [1, 4, 4, 1], [0, 0, 0])
+    ref = to_oracle(tt)
+    y = T._tt_bond_truncate_(tt, 1, max_bond=2, truncerr=0.0)
+    O.tt_bond_truncate_(ref, 1, max_bond=2)
+    assert tt.ttv_rks[1] <= 2 and tt.ttv_rks == ref.ttv_rks
+    r = tt.ttv_rks[1]
+    assert tt.ttv_vec[0].shape == (2, 1, r) and tt.ttv_vec[1].shape == (2, r, 4)
+    assert y.ttv_rks[1] == tt.ttv_rks[1] and y.ttv_vec[0].shape == tt.ttv_vec[0].shape
+    assert np.allclose(O.ttv_to_tensor(to_oracle(tt)), O.ttv_to_tensor(ref), atol=1e-12)
+
+    u, v, p, q = [1.2, -0.5], [0.7, 0.3], [2.0, 3.0], [4.0, 5.0]
+    c1, c2 = np.zeros((2, 1, 2)), np.zeros((2, 2, 1))
+    for s in range(2):
+        for g in range(2):
+            c1[s, 0, g] = p[g] * u[s]
+            c2[s, g, 0] = q[g] * v[s]
+    tt2 = T.TTvector(2, [c1, c2], (2, 2), [1, 2, 1], [0, 0])
+    T0 = O.ttv_to_tensor(to_oracle(tt2))
+    y2 = T._tt_bond_truncate_(tt2, 1, max_bond=1)
+    assert tt2.ttv_rks[1] == 1 and tt2.ttv_vec[0].shape == (2, 1, 1) and tt2.ttv_vec[1].shape == (2, 1, 1) and y2.ttv_rks[1] == 1
+    assert np.allclose(O.ttv_to_tensor(to_oracle(tt2)), T0, atol=1e-12)
+    tt3 = T.rand_tt((2, 2, 2), [1, 2, 2, 1], seed=4)
+    with pytest.raises(AssertionError):
+        T._tt_bond_truncate_(tt3, 0)
+    with pytest.raises(AssertionError):
+        T._tt_bond_truncate_(tt3, tt3.N)
+
+
+def test_tt_compress_reference_behaviour(T, caplog):
+    tt = T.rand_tt((2, 2, 2), [1, 2, 2, 1], seed=6)                     # test/test_tt_tools.jl:500-574
+    before, T0 = list(tt.ttv_rks), O.ttv_to_tensor(to_oracle(tt))
+    y = T.tt_compress_(tt, 10, sweeps=1)
+    assert y is tt and tt.ttv_rks == before
+    assert np.allclose(O.ttv_to_tensor(to_oracle(tt)), T0, atol=1e-12)
+    tt = T.rand_tt((2, 2, 2, 2), [1, 4, 4, 4, 1], seed=7)
+    y = T.tt_compress_(tt, 2, sweeps=1)
+    assert y is tt and max(tt.ttv_rks) <= 2
+    for i in range(4):
+        assert tt.ttv_vec[i].shape == (2, tt.ttv_rks[i], tt.ttv_rks[i + 1])
+    with pytest.raises(AssertionError):
+        T.tt_compress_(T.rand_tt((2, 2, 2), [1, 2, 2, 1], seed=8), 2, sweeps=0)
+    tt = T.rand_tt((2, 2, 2), [1, 3, 3, 1], seed=9)
+    ref = to_oracle(tt)
+    assert T.tt_compress_(tt, 3, sweeps=2, truncerr=0.0) is tt
+    O.tt_compress_(ref, 3, sweeps=2)
+    assert np.allclose(O.ttv_to_tensor(to_oracle(tt)), O.ttv_to_tensor(ref), atol=1e-12)
+    import logging
+    with caplog.at_level(logging.INFO, logger="TensorTrainNumerics"):
+        T.tt_compress_(T.rand_tt((2, 2, 2), [1, 2, 2, 1], seed=10), 2, verbose=True)
+    msgs = [r.getMessage() for r in caplog.records]
+    assert any("TT compress: sweep 1 (L→R)" in m for m in msgs) and any("TT compress: sweep 1 (R→L)" in m for m in msgs)
+
+
+def test_compress_compressible_inputs(T):
+    """Restates test/test_qtt_multidim.jl:577-614 with closed-form inputs (truncerr = 1e-12)."""
+    d = 12
+    e = T.qtt_exp(d, alpha=-1.0)
+    padded = (e + 0.5 * e) + ((-0.25) * e + e)
+    assert max(padded.ttv_rks) == 4
+    ref = to_oracle(padded)
+    T.tt_compress_(padded, 10, truncerr=1e-12)
+    O.tt_compress_(ref, 10, truncerr=1e-12)
+    assert padded.ttv_rks == ref.ttv_rks and max(padded.ttv_rks) == 1
+    x = np.linspace(0, 1, 2 ** d)
+    assert np.max(np.abs(T.qtt_to_vector(padded) - 2.25 * np.exp(-x))) < 1e-10
+    d = 10
+    s = T.qtt_sin(d, lam=2.0)
+    big = T.hadamard(s, T.qtt_cos(d, lam=3.0)) + 1e-3 * T.hadamard(s, s)
+    dense = T.qtt_to_vector(big)
+    refb = to_oracle(big)
+    T.tt_compress_(big, 8, truncerr=1e-12)
+    O.tt_compress_(refb, 8, truncerr=1e-12)
+    assert big.ttv_rks == refb.ttv_rks and max(big.ttv_rks) <= 8
+    assert np.max(np.abs(T.qtt_to_vector(big) - dense)) < 1e-8
+
+
+@pytest.mark.parametrize("d,r,seed", [(8, 6, 1), (12, 16, 2), (20, 32, 20)])
+def test_apply_compress_vs_oracle(T, d, r, seed):
+    """Δ(d) * random rank-r train, then tt_compress!(·, r): ranks exact, per-bond singular values 1e-10,
+    cores equal up to one sign per bond, tensor difference ≤ 1e-9 (config 2 is d=20, r=32)."""
+    x = T.rand_tt((2,) * d, r, seed=seed)
+    A = T.Delta(d)
+    dA, dx = T.DeviceTTO(A), T.DeviceTT.from_host(x)
+    dy = T.DeviceTT(x.ttv_dims, [a * b for a, b in zip(A.tto_rks, x.ttv_rks)])
+    dy.capture_singular_values(True)
+    T.device.apply_compress(dA, dx, dy, r, 0.0, 1)
+    T.device.compress_status(dy)
+    got = dy.download()
+    sv = []
+    ref = O.tt_compress_(O.apply(O.Delta(d), to_oracle(x)), r, svals_out=sv)
+    assert got.ttv_rks == ref.ttv_rks
+    for i, s_ref in enumerate(sv):
+        s = dy.singular_values(0, i)
+        assert len(s) == len(s_ref)
+        assert np.allclose(s, s_ref, rtol=1e-10, atol=1e-13 * s_ref[0]), f"bond step {i}"
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
+    assert sign_fix_compare(to_oracle(got), ref) <= 1e-7
+
+
+def test_rk4_step_from_apply_round(T):
+    """test/test_euler.jl:269-298: one RK4 step assembled from apply, +, scalar*, tt_compress! vs dense RK4."""
+    rng = np.random.default_rng(7)
+    d = 4
+    hh = 1 / d ** 2
+    A = T.toeplitz_to_qtto(-2.0, 1.0, 1.0, d)
+    A.tto_vec[0] = (-hh ** 2) * A.tto_vec[0]
+    u0 = to_product(O.rand_tt((2,) * d, [1, 2, 2, 2, 1], rng))
+    h, mb = 0.05, 8
+    k1 = A * u0
+    k2 = A * T.tt_compress_(u0 + (h / 2) * k1, mb)
+    k3 = A * T.tt_compress_(u0 + (h / 2) * k2, mb)
+    k4 = A * T.tt_compress_(u0 + h * k3, mb)
+    incr = (h / 6) * T.tt_compress_(k1 + 2 * k2 + 2 * k3 + k4, mb)
+    sol = T.tt_compress_(u0 + incr, mb)
+    Ad, ud = O.qtto_to_matrix(to_oracle(A)), T.qtt_to_vector(u0)
+    K1 = Ad @ ud
+    K2 = Ad @ (ud + h / 2 * K1)
+    K3 = Ad @ (ud + h / 2 * K2)
+    K4 = Ad @ (ud + h * K3)
+    refv = ud + h / 6 * (K1 + 2 * K2 + 2 * K3 + K4)
+    assert np.linalg.norm(T.qtt_to_vector(sol) - refv) / np.linalg.norm(refv) < 1e-6
+
+
+def test_batched_handles_independent_trains(T):
+    """A batch of different trains through apply + round: every train equals its own oracle result."""
+    d, r, B = 10, 8, 5
+    A = T.Delta(d)
+    xs = [T.rand_tt((2,) * d, r, seed=100 + b) for b in range(B)]
+    dA = T.DeviceTTO(A)
+    dx = T.DeviceTT((2,) * d, xs[0].ttv_rks, batch=B)
+    for b, x in enumerate(xs):
+        dx.upload(b, x)
+    dy = T.DeviceTT((2,) * d, [a * c for a, c in zip(A.tto_rks, xs[0].ttv_rks)], batch=B)
+    T.device.apply_compress(dA, dx, dy, r, 0.0, 1)
+    T.device.compress_status(dy)
+    nrm = T.device.norm(dy)
+    for b, x in enumerate(xs):
+        ref = O.tt_compress_(O.apply(O.Delta(d), to_oracle(x)), r)
+        got = dy.download(b)
+        assert got.ttv_rks == ref.ttv_rks
+        assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
+        assert math.isclose(nrm[b], O.norm(ref), rel_tol=1e-9)
+
+
+def test_headline_config_properties(T):
+    """C3 (d=30, rank 64): the oracle needs ~0.2 s here, so compare directly AND check size-independent
+    properties: ranks, idempotence of a second round at the same max_bond, norm never increases."""
+    d, r = 30, 64
+    x = T.rand_tt((2,) * d, r, seed=30)
+    A = T.Delta(d)
+    dA, dx = T.DeviceTTO(A), T.DeviceTT.from_host(x)
+    dy = T.DeviceTT(x.ttv_dims, [a * b for a, b in zip(A.tto_rks, x.ttv_rks)])
+    T.device.apply(dA, dx, dy)
+    n_before = T.device.norm(dy)[0]
+    T.device.tt_compress_(dy, r)
+    T.device.compress_status(dy)
+    got = dy.download()
+    assert got.ttv_rks == x.ttv_rks
+    ref = O.tt_compress_(O.apply(O.Delta(d), to_oracle(x)), r)
+    assert got.ttv_rks == ref.ttv_rks
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
+    n_after = T.device.norm(dy)[0]
+    assert n_after <= n_before * (1 + 1e-12)
+    # second round at the same rank: every merged matrix already has rank <= r, so the tensor is unchanged
+    T.device.tt_compress_(dy, r)
+    again = dy.download()
+    assert again.ttv_rks == got.ttv_rks
+    assert tt_rel_diff(to_oracle(again), to_oracle(got)) <= 1e-10

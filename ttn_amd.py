@@ -1,0 +1,11 @@
+"""Importable alias for the package directory `tensortrainnumerics.jl_amd/` (its name contains a
+dot, so `import` cannot address it directly):  `import ttn_amd`."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tensortrainnumerics.jl_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)
