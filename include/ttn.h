@@ -125,6 +125,12 @@ int ttn_timer_end(float* ms);   /* synchronises */
 int ttn_event_record(int64_t slot);
 int ttn_event_elapsed(int64_t slot_a, int64_t slot_b, float* ms);
 
+/* diagnostic: with TTN_PROF=1 in the environment ttn_compress records s_memtime ticks per phase
+ * (merge, scale, LQ, Jacobi, sort/rank, split) for every train; out8 receives train b's 8 counters */
+int ttn_prof_get(int64_t b, int64_t* out8);
+/* per bond step (first 120 steps): (p << 32) | jacobi_sweeps, p = short side of the merged matrix */
+int ttn_prof_steps(int64_t b, int64_t* out120);
+
 /* ---- stateless host-pointer entry points: the literal drop-ins for one train --------------------
  * Each uploads, runs the handle op above, and downloads.  Output cores are caller-allocated:
  *   apply     : Y_cores[k] sized n_k*(A_rks[k]*X_rks[k])*(A_rks[k+1]*X_rks[k+1])   (as zeros_tt would)
@@ -132,7 +138,7 @@ int ttn_event_elapsed(int64_t slot_a, int64_t slot_b, float* ms);
  *   add       : Z_cores[k] sized with ranks rx+ry (ends forced to 1)
  *   compress  : in/out cores sized for the INPUT ranks; `rks` is updated in place; cores are rewritten
  *               compactly with the new ranks (the Julia shim re-wraps them to exact-size Arrays)
- *   orthogonalize: Y_cores sized for r_and_d_to_rks(X_rks) ; Y_rks / Y_ot are outputs
+ *   orthogonalize: Y_cores sized for X_rks (output ranks never exceed the input's) ; Y_rks / Y_ot are outputs
  */
 int ttn_apply_f64(int64_t d, const int64_t* dims,
                   const double* const* A_cores, const int64_t* A_rks,

@@ -1,0 +1,127 @@
+# TTNBackend.jl — the Julia-side binding a TensorTrainNumerics.jl maintainer would add to route the
+# Float64 hot path through libttn_hip.so (include/ttn.h).  NOT executed in this repository: the build
+# image has no Julia runtime (see DESIGN.md §2); the same C ABI is exercised through ctypes by
+# tensortrainnumerics.jl_amd/tt.py, which mirrors this file function for function.
+#
+# Only `TTvector{Float64}` / `TToperator{Float64}` methods are overloaded; every other eltype
+# (ComplexF64, Float32, Int — test/test_tt_tools.jl:576-596) falls through to the generic Julia methods.
+module TTNBackend
+
+using TensorTrainNumerics
+import TensorTrainNumerics: TTvector, TToperator, orthogonalize, tt_compress!, hadamard, add!, r_and_d_to_rks
+import Base: *, +
+
+const LIB = get(ENV, "TTN_LIB", joinpath(@__DIR__, "..", "tensortrainnumerics.jl_amd", "libttn_hip.so"))
+
+# return-code contract of include/ttn.h: 0 ok, <0 argument error (AssertionError in the reference), >0 HIP error
+function _chk(rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:ttn_last_error_string, LIB), Cstring, ()))
+    (-4 <= rc <= -1) && throw(AssertionError(msg))      # tt_operations.jl:11,102,240,344; tt_tools.jl:513,744,773
+    error("ttn error $rc: $msg")
+end
+
+_ptrs(v::Vector{<:Array{Float64}}) = Ptr{Float64}[pointer(c) for c in v]
+_dims(x) = Int64[x...]
+
+# *(A::TToperator, v::TTvector)  — src/tt_operations.jl:101-111
+function *(A::TToperator{Float64, N}, v::TTvector{Float64, N}) where {N}
+    @assert A.tto_dims == v.ttv_dims "Incompatible dimensions"
+    y = zeros_tt(Float64, A.tto_dims, A.tto_rks .* v.ttv_rks)
+    pa, px, py = _ptrs(A.tto_vec), _ptrs(v.ttv_vec), _ptrs(y.ttv_vec)
+    GC.@preserve A v y pa px py _chk(ccall((:ttn_apply_f64, LIB), Cint,
+        (Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}),
+        N, _dims(A.tto_dims), pa, A.tto_rks, px, v.ttv_rks, py))
+    return y
+end
+
+# dot(A, B) — src/tt_operations.jl:239-250
+function TensorTrainNumerics.dot(A::TTvector{Float64, N}, B::TTvector{Float64, N}) where {N}
+    @assert A.ttv_dims == B.ttv_dims "TT dimensions are not compatible"
+    out = Ref{Float64}(0.0)
+    pa, pb = _ptrs(A.ttv_vec), _ptrs(B.ttv_vec)
+    GC.@preserve A B pa pb _chk(ccall((:ttn_dot_f64, LIB), Cint,
+        (Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ref{Float64}),
+        N, _dims(A.ttv_dims), pa, A.ttv_rks, pb, B.ttv_rks, out))
+    return out[]
+end
+
+# hadamard(x, y) — src/tt_operations.jl:343-361
+function hadamard(x::TTvector{Float64, N}, y::TTvector{Float64, N}) where {N}
+    @assert x.ttv_dims == y.ttv_dims "Incompatible TT dimensions"
+    z = zeros_tt(Float64, x.ttv_dims, x.ttv_rks .* y.ttv_rks)
+    px, py, pz = _ptrs(x.ttv_vec), _ptrs(y.ttv_vec), _ptrs(z.ttv_vec)
+    GC.@preserve x y z px py pz _chk(ccall((:ttn_hadamard_f64, LIB), Cint,
+        (Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}),
+        N, _dims(x.ttv_dims), px, x.ttv_rks, py, y.ttv_rks, pz))
+    return z
+end
+
+# +(x, y) — src/tt_operations.jl:10-35
+function +(x::TTvector{Float64, N}, y::TTvector{Float64, N}) where {N}
+    @assert x.ttv_dims == y.ttv_dims "Incompatible dimensions"
+    rks = x.ttv_rks + y.ttv_rks; rks[1] = 1; rks[end] = 1
+    z = zeros_tt(Float64, x.ttv_dims, rks)
+    px, py, pz = _ptrs(x.ttv_vec), _ptrs(y.ttv_vec), _ptrs(z.ttv_vec)
+    GC.@preserve x y z px py pz _chk(ccall((:ttn_add_f64, LIB), Cint,
+        (Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Ptr{Float64}}),
+        N, _dims(x.ttv_dims), px, x.ttv_rks, py, y.ttv_rks, pz))
+    return z
+end
+
+# add!(x, y) — src/tt_operations.jl:37-66 (rebinds the fields of x)
+function add!(x::TTvector{Float64, N}, y::TTvector{Float64, N}) where {N}
+    z = x + y
+    x.ttv_vec = z.ttv_vec; x.ttv_rks = z.ttv_rks; x.ttv_ot = z.ttv_ot
+    return x
+end
+
+# orthogonalize(x; i=1) — src/tt_tools.jl:511-543
+function orthogonalize(x::TTvector{Float64, N}; i = 1::Int) where {N}
+    @assert(1 ≤ i ≤ x.N, DimensionMismatch("Impossible orthogonalization"))
+    y = zeros_tt(Float64, x.ttv_dims, x.ttv_rks)    # max-size buffers (output ranks never exceed the input's)
+    yr = zeros(Int64, N + 1); yot = zeros(Int64, N)
+    px, py = _ptrs(x.ttv_vec), _ptrs(y.ttv_vec)
+    GC.@preserve x y px py _chk(ccall((:ttn_orthogonalize_f64, LIB), Cint,
+        (Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Int64, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}),
+        N, _dims(x.ttv_dims), px, x.ttv_rks, i, py, yr, yot))
+    # the library writes each core compactly with the NEW ranks at the start of its buffer: re-wrap
+    for k in 1:N
+        n = x.ttv_dims[k]
+        y.ttv_vec[k] = reshape(vec(y.ttv_vec[k])[1:(n * yr[k] * yr[k + 1])], n, yr[k], yr[k + 1])
+    end
+    y.ttv_rks .= yr; y.ttv_ot .= yot
+    return y
+end
+
+# tt_compress!(ψ, max_bond; truncerr, sweeps, verbose) — src/tt_tools.jl:772-789.
+# Mutates ψ.ttv_vec[k] slots and ψ.ttv_rks IN PLACE (QTTvector wrappers share those arrays,
+# src/qtt_tools.jl:783-786) and returns ψ itself (test/test_tt_tools.jl:514).
+function tt_compress!(ψ::TTvector{Float64, N}, max_bond::Int; truncerr::Real = 0.0, sweeps::Int = 1, verbose::Bool = false) where {N}
+    @assert(sweeps ≥ 1, "sweeps must be >= 1")
+    if verbose                               # the two log lines test/test_tt_tools.jl:572 asserts on
+        for sw in 1:sweeps
+            @info "TT compress: sweep $sw (L→R)"
+            @info "TT compress: sweep $sw (R→L)"
+        end
+    end
+    bufs = [copy(c) for c in ψ.ttv_vec]
+    rks = copy(ψ.ttv_rks)
+    pb = _ptrs(bufs)
+    GC.@preserve bufs pb _chk(ccall((:ttn_compress_f64, LIB), Cint,
+        (Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Int64, Float64, Int64),
+        N, _dims(ψ.ttv_dims), pb, rks, min(max_bond, typemax(Int64) >> 1), Float64(truncerr), sweeps))
+    for k in 1:N
+        n = ψ.ttv_dims[k]
+        ψ.ttv_vec[k] = reshape(vec(bufs[k])[1:(n * rks[k] * rks[k + 1])], n, rks[k], rks[k + 1])
+    end
+    ψ.ttv_rks .= rks
+    return ψ
+end
+
+# Device-resident chains (Krylov / RK4 inner loops, src/solvers/euler.jl:55,199-204) use the handle API:
+#   h = Ref{Ptr{Cvoid}}(); ccall((:ttn_tt_create, LIB), Cint, (Int64, Ptr{Int64}, Ptr{Int64}, Int64, Ref{Ptr{Cvoid}}), ...)
+#   ccall((:ttn_apply_compress, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Int64), A, x, y, r, 0.0, 1)
+# so that tt_compress!(A*x, r) never crosses PCIe.
+
+end # module

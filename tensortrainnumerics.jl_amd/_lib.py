@@ -66,6 +66,8 @@ SIGNATURES = {
     "ttn_sv_get": (C.c_int, [handle, i64, i64, p_f64, i64, p_i64]),
     "ttn_timer_begin": (C.c_int, []),
     "ttn_timer_end": (C.c_int, [C.POINTER(C.c_float)]),
+    "ttn_prof_get": (C.c_int, [i64, p_i64]),
+    "ttn_prof_steps": (C.c_int, [i64, p_i64]),
     "ttn_event_record": (C.c_int, [i64]),
     "ttn_event_elapsed": (C.c_int, [i64, i64, C.POINTER(C.c_float)]),
     "ttn_apply_f64": (C.c_int, [i64, p_i64, pp_f64, p_i64, pp_f64, p_i64, pp_f64]),

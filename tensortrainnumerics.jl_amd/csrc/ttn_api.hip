@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -29,6 +30,8 @@ int* g_status = nullptr;      // per-train status + sweep stats (2 * g_status_ca
 int g_status_cap = 0;
 double* g_dout = nullptr;     // per-train double outputs (dot)
 std::vector<hipEvent_t> g_slots;   // ttn_event_record slots
+int g_prof_batch = 0;
+long long* g_prof = nullptr;       // TTN_PROF=1 diagnostic phase counters of the last compress launch
 int g_dout_cap = 0;
 
 int fail(int code, const char* what) {
@@ -566,6 +569,16 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     P.sv_steps = steps;
     P.status = g_status;
     P.sweep_stats = g_status + psi->batch;
+    P.prof = nullptr;
+    if (getenv("TTN_PROF")) {
+        static long long* d_prof = nullptr; static int prof_cap = 0;
+        if (prof_cap < psi->batch) { if (d_prof) hipFree(d_prof); HIPCHK(hipMalloc((void**)&d_prof, sizeof(long long) * 128 * psi->batch)); prof_cap = psi->batch; }
+        HIPCHK(hipMemsetAsync(d_prof, 0, sizeof(long long) * 128 * psi->batch, g_stream));
+        g_prof_batch = psi->batch;
+        P.prof = d_prof; g_prof = d_prof;
+    }
+    { const char* e = getenv("TTN_JTOL"); P.jtol_mult = e ? atof(e) : 1.0; }
+    { const char* e = getenv("TTN_JNEG"); P.jneg_mult = e ? atof(e) : 1.0; }
     hipLaunchKernelGGL(k_compress, dim3(psi->batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, P);
     HIPCHK(hipGetLastError());
     // host rank bounds after truncation
@@ -626,6 +639,28 @@ int ttn_compress_status(ttn_tt_t psi, int64_t* total_jacobi_sweeps) {
     return check_status(psi->batch);
 }
 
+// diagnostic: per-phase cycle counters (100 MHz s_memtime ticks) of train b from the last TTN_PROF=1 compress launch
+int ttn_prof_get(int64_t b, int64_t* out8) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!g_prof || !out8) return fail(TTN_ERR_ARG, "no profile (set TTN_PROF=1)");
+    long long tmp[8];
+    HIPCHK(hipMemcpyAsync(tmp, g_prof + 8 * b, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (int i = 0; i < 8; ++i) out8[i] = tmp[i];
+    return TTN_OK;
+}
+int ttn_prof_steps(int64_t b, int64_t* out120) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!g_prof || !out120) return fail(TTN_ERR_ARG, "no profile (set TTN_PROF=1)");
+    long long tmp[120];
+    HIPCHK(hipMemcpyAsync(tmp, g_prof + 8LL * g_prof_batch + 120 * b, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (int i = 0; i < 120; ++i) out120[i] = tmp[i];
+    return TTN_OK;
+}
+
 int ttn_dot(ttn_tt_t a, ttn_tt_t b, double* out) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     NEED_INIT();
@@ -669,9 +704,9 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     if (x == y) return fail(TTN_ERR_ARG, "ttn_orthogonalize: output must not alias the input");
     const int d = x->d;
     if (center < 1 || center > d) return fail(TTN_ERR_CENTER, "Impossible orthogonalization");
-    // y ranks start from r_and_d_to_rks(x.rks, dims) and can only shrink
-    std::vector<int64_t> yb(d + 1);
-    ttn_r_and_d_to_rks(d, x->dims.data(), d + 1, x->bound.data(), 1024, yb.data());
+    // y ranks start from r_and_d_to_rks(x.rks, dims) but a left QR step sets r_{j+1} = min(rows, cols), which can
+    // exceed that cap (the reference reassigns the rank, tt_tools.jl:522); they never exceed x's own ranks.
+    std::vector<int64_t> yb(x->bound);
     for (int m = 0; m <= d; ++m) if (y->cap[m] < yb[m]) return fail(TTN_ERR_CAPACITY, "ttn_orthogonalize: destination capacity too small");
     long long rmax = 1, nmax = 1;
     for (int m = 0; m <= d; ++m) rmax = std::max<long long>(rmax, x->bound[m]);
@@ -816,11 +851,9 @@ int ttn_orthogonalize_f64(int64_t d, const int64_t* dims, const double* const* X
     if (!dims || !X_cores || !X_rks || !Y_cores || !Y_rks || !Y_ot || d < 1) return fail(TTN_ERR_ARG, "bad argument");
     if (center < 1 || center > d) return fail(TTN_ERR_CENTER, "Impossible orthogonalization");
     TmpTT x, y;
-    std::vector<int64_t> yr(d + 1);
-    ttn_r_and_d_to_rks(d, dims, d + 1, X_rks, 1024, yr.data());
     if ((rc = ttn_tt_create(d, dims, X_rks, 1, &x.h))) return rc;
     if ((rc = ttn_tt_upload(x.h, 0, X_cores, X_rks, nullptr))) return rc;
-    if ((rc = ttn_tt_create(d, dims, yr.data(), 1, &y.h))) return rc;
+    if ((rc = ttn_tt_create(d, dims, X_rks, 1, &y.h))) return rc;
     if ((rc = ttn_orthogonalize(x.h, center, y.h))) return rc;
     if ((rc = ttn_tt_ranks(y.h, 0, Y_rks, Y_ot))) return rc;
     return ttn_tt_download(y.h, 0, Y_cores);

@@ -223,12 +223,23 @@ __device__ __noinline__ void wg_lq_factor(int p, int q, double* M2, int ld, doub
 // ordering, one wave per column pair, lanes over rows.  Returns the number of sweeps used
 // (negative if the sweep limit was hit).  X may live in LDS or in global memory.
 // -------------------------------------------------------------------------------------------------
-__device__ __noinline__ int wg_jacobi_cols(int m, int p, double* X, int ldx, int* flag /*LDS*/) {
+__device__ __noinline__ int wg_jacobi_cols(int m, int p, double* X, int ldx, int* flag /*LDS*/, double* red /*LDS*/, double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
-    if (p < 2) return 0;
+    if (p < 2) { if (tid == 0) *aneg_out = 0.0; __syncthreads(); return 0; }
     const int pe = p + (p & 1);               // even number of slots; slot p (if odd) is a bye
     const int half = pe >> 1;
-    const double tol = sqrt((double)m) * DBL_EPSILON;
+    const double tol = tol_mult * sqrt((double)m) * DBL_EPSILON;
+    // columns whose norm is below eps*sqrt(m)*(largest column norm) carry singular values below what fp64
+    // can resolve against sigma_max; they are left alone (rotating pure rounding noise never converges)
+    double amax = 0.0;
+    for (int c = wave; c < p; c += nwaves) {
+        double a = 0.0;
+        for (int r = lane; r < m; r += 64) { const double v = X[(long long)c * ldx + r]; a = fma(v, v, a); }
+        amax = fmax(amax, wave_sum(a));
+    }
+    amax = wg_max(amax, red);
+    const double aneg = neg_mult * neg_mult * (double)m * DBL_EPSILON * DBL_EPSILON * amax;
+    if (tid == 0) *aneg_out = aneg;
     int sweep = 0;
     for (; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
         if (tid == 0) *flag = 0;
@@ -249,7 +260,7 @@ __device__ __noinline__ int wg_jacobi_cols(int m, int p, double* X, int ldx, int
                     a = fma(u, u, a); b = fma(v, v, b); g = fma(u, v, g);
                 }
                 a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
-                if (a == 0.0 || b == 0.0) continue;
+                if (a <= aneg || b <= aneg) continue;
                 if (fabs(g) <= tol * sqrt(a) * sqrt(b)) continue;
                 // rotation annihilating g (Rutishauser formulas)
                 const double zeta = (b - a) / (2.0 * g);
@@ -274,6 +285,148 @@ __device__ __noinline__ int wg_jacobi_cols(int m, int p, double* X, int ldx, int
     return -sweep;
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Fast path of the one-sided Jacobi for p <= 128 columns of length m <= 128, X resident in LDS with a
+// FIXED leading dimension of 128 doubles (column c at X + 128*c).
+//   * a wave works on 4 column pairs at once: 16 lanes per pair, lane `sub` owns rows sub + 16*t;
+//     groups 1 and 3 walk t rotated by one so the two pairs of a 32-lane half hit disjoint LDS banks;
+//   * the 64 pairs of a round-robin round are spread over the 16 waves (pair = 4*wave + group);
+//   * squared column norms are cached in LDS (recomputed at the start of every sweep, updated by
+//     a' = a - t*g, b' = b + t*g), so a rotation costs one dot product;
+//   * reductions over the 16 lanes of a pair are 4 DPP steps (quad_perm, row_half_mirror, row_mirror);
+//   * the rotation (t, c, s) uses v_rcp_f64 / v_rsq_f64 seeds: t only needs ~2^-40 relative accuracy
+//     (it sets the speed of convergence), c = rsqrt(1+t^2) gets two Newton steps so that c^2+s^2 = 1
+//     to rounding (that is what makes every applied rotation orthogonal, i.e. backward stable).
+// -------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) double lds_f64;
+
+template <int CTRL>
+__device__ inline double dpp_mov_f64(double v) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, true);
+    return r.d;
+}
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ inline double row16_sum(double v) {
+    v += dpp_mov_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);    // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);    // row_mirror
+    return v;
+}
+__device__ inline double fast_rcp(double x) {       // ~2^-50 relative after one Newton step
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+__device__ inline double fast_rsqrt2(double w) {    // two Newton steps on v_rsq_f64: full fp64 accuracy
+    double y = __builtin_amdgcn_rsq(w);
+    double h = 0.5 * w;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+__device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* nrm2g, int* flag, double* red,
+                                             double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    if (p < 2) { if (tid == 0) *aneg_out = 0.0; __syncthreads(); return 0; }
+    lds_f64* X = (lds_f64*)Xg;
+    lds_f64* nrm2 = (lds_f64*)nrm2g;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int pe = p + (p & 1), half = pe >> 1;
+    const int nt = (m + 15) >> 4;                       // row chunks of 16
+    const int trot = (grp & 1);                          // groups 1,3 start one chunk later (bank spreading)
+    const double tol = tol_mult * sqrt((double)m) * DBL_EPSILON;
+    const double tol2 = tol * tol;
+    double aneg = 0.0;
+    int sweep = 0;
+    for (; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+        // ---- refresh the cached squared norms ----
+        double amax = 0.0;
+        for (int c = wave * 4 + grp; c < p; c += nwaves * 4) {
+            double a = 0.0;
+            for (int t = 0; t < nt; ++t) {
+                const int r = sub + 16 * t;
+                const double v = (r < m) ? X[c * 128 + r] : 0.0;
+                a = fma(v, v, a);
+            }
+            a = row16_sum(a);
+            if (sub == 0) nrm2[c] = a;
+            amax = fmax(amax, a);
+        }
+        if (sweep == 0) {
+            amax = wg_max(amax, red);
+            aneg = neg_mult * neg_mult * (double)m * DBL_EPSILON * DBL_EPSILON * amax;
+            if (tid == 0) *aneg_out = aneg;
+        }
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        int rotated = 0;
+        for (int round = 0; round < pe - 1; ++round) {
+            const int kk = wave * 4 + grp;               // pair slot of this 16-lane group
+            int i = 0, j = 0;
+            bool act = kk < half;
+            if (act) {
+                if (kk == 0) { i = round; j = pe - 1; }
+                else {
+                    i = round + kk; if (i >= pe - 1) i -= pe - 1;
+                    j = round + pe - 1 - kk; if (j >= pe - 1) j -= pe - 1;
+                }
+                if (i > j) { const int t_ = i; i = j; j = t_; }
+                act = j < p;
+            }
+            if (act) {
+                lds_f64* xi = X + i * 128;
+                lds_f64* xj = X + j * 128;
+                double u[8], v[8];
+                double g = 0.0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    int tt = t + trot; if (tt >= 8) tt -= 8;
+                    const int r = sub + 16 * tt;
+                    const bool in = (tt < nt) && (r < m);
+                    u[t] = in ? xi[r] : 0.0;
+                    v[t] = in ? xj[r] : 0.0;
+                    g = fma(u[t], v[t], g);
+                }
+                g = row16_sum(g);
+                const double a = nrm2[i], b = nrm2[j];
+                const bool rot = (a > aneg) && (b > aneg) && (g * g > tol2 * a * b);
+                if (rot) {
+                    const double zeta = (b - a) * fast_rcp(2.0 * g);
+                    const double w = fma(zeta, zeta, 1.0);
+                    const double sq = w * fast_rsqrt2(w);                  // sqrt(1 + zeta^2)
+                    const double t_ = copysign(fast_rcp(fabs(zeta) + sq), zeta);
+                    const double cs = fast_rsqrt2(fma(t_, t_, 1.0));
+                    const double sn = cs * t_;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        int tt = t + trot; if (tt >= 8) tt -= 8;
+                        const int r = sub + 16 * tt;
+                        if ((tt < nt) && (r < m)) {
+                            xi[r] = fma(cs, u[t], -sn * v[t]);
+                            xj[r] = fma(sn, u[t], cs * v[t]);
+                        }
+                    }
+                    if (sub == 0) { nrm2[i] = fmax(a - t_ * g, 0.0); nrm2[j] = b + t_ * g; }
+                    rotated = 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (rotated) atomicOr(flag, 1);
+        __syncthreads();
+        const int any = *flag;
+        __syncthreads();
+        if (!any) return sweep + 1;
+    }
+    return -sweep;
+}
+
 // -------------------------------------------------------------------------------------------------
 // Parameters of the compress / bond-truncate kernel
 // -------------------------------------------------------------------------------------------------
@@ -290,10 +443,13 @@ struct CompressArgs {
     int sv_steps;
     int* status;           // [batch] device: 0 ok, 1 = Jacobi did not converge
     int* sweep_stats;      // [batch] device: total Jacobi sweeps (diagnostics)
+    double jtol_mult;      // Jacobi convergence threshold = jtol_mult * sqrt(m) * eps
+    long long* prof;       // null, or [batch][8] cycle counters per phase (diagnostic builds of the launch only)
+    double jneg_mult;      // columns below jneg_mult * sqrt(m) * eps * max column norm are treated as zero
 };
 
 #define COMPRESS_LDS_X_DOUBLES (128 * 128)
-#define COMPRESS_LDS_BYTES ((COMPRESS_LDS_X_DOUBLES + 32 + 2 * QR_NB * QR_NB + QR_NB + 8 + 8) * sizeof(double))
+#define COMPRESS_LDS_BYTES ((COMPRESS_LDS_X_DOUBLES + 32 + 2 * QR_NB * QR_NB + QR_NB + 8 + 8 + 128) * sizeof(double))
 
 // One bond step on (core_k, core_{k+1}), 0-based k.  src/tt_tools.jl:743-768 with the effective
 // _svdtrunc of src/tt_cross_interpolation.jl:149-166.
@@ -322,6 +478,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
     double* taus = Ss + QR_NB * QR_NB;                    // QR_NB
     double* scal = taus + QR_NB;                          // 8 misc doubles
     int* iflag = reinterpret_cast<int*>(scal + 8);        // 8 ints
+    double* nrm2 = scal + 16;                             // 128 cached squared column norms
     // ---- global scratch carve-up ----
     double* scr = P.scratch + (long long)b * P.scratch_stride;
     const long long pq = (long long)P.pmax * P.qmax;
@@ -335,10 +492,13 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
     double* sigs = sig + P.pmax;                          // pmax sorted
     int* perm = reinterpret_cast<int*>(sigs + P.pmax);    // pmax ints: sorted position -> column
 
+    long long t_prev = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define PROF_MARK(slot) if (P.prof) { __syncthreads(); if (tid == 0) { long long t_now = (long long)__builtin_amdgcn_s_memtime(); P.prof[(long long)b * 8 + (slot)] += t_now - t_prev; t_prev = t_now; } }
     // ---- 1. merge: M = A' * B'  (p x q) ----
     const View Mv = mkview(M, plain(q), plain(1));
     wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds);
 
+    PROF_MARK(0)
     // ---- 2. scale to max|M| = 1 (guards the squared norms in Jacobi against over/underflow) ----
     double mx = 0.0;
     for (long long e = tid; e < (long long)p * q; e += TTN_WG) mx = fmax(mx, fabs(M[e]));
@@ -353,29 +513,35 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
     }
     __syncthreads();
 
+    PROF_MARK(1)
     // ---- 3. triangular factor: L (p x p) with M = L Q ----
     if (need_lq) wg_lq_factor(p, q, M2, q, Vb, Wb, lds, Ts, Ss, taus, red);
 
+    PROF_MARK(2)
     // ---- 4. Jacobi on the columns of L (or of M itself when square) ----
-    const bool x_in_lds = (long long)p * p <= COMPRESS_LDS_X_DOUBLES;
+    const bool x_in_lds = p <= 128;                       // fast path: X in LDS with leading dimension 128
     double* X = x_in_lds ? ldsX : Xg;
+    const int ldx = x_in_lds ? 128 : p;
     const double* Lsrc = need_lq ? M2 : M;               // row-major, ld = q
     for (int e = tid; e < p * p; e += TTN_WG) {
-        const int r = e % p, c = e / p;                   // X[r + p*c] = L[r][c]
+        const int r = e % p, c = e / p;                   // X[r + ldx*c] = L[r][c]
         const double v = Lsrc[(long long)r * q + c];
-        X[e] = (need_lq && c > r) ? 0.0 : v;
+        X[(long long)c * ldx + r] = (need_lq && c > r) ? 0.0 : v;
     }
     __syncthreads();
-    const int nsw = wg_jacobi_cols(p, p, X, p, iflag);
+    const int nsw = (x_in_lds && P.jneg_mult < 100.0) ? wg_jacobi_lds128(p, p, X, nrm2, iflag, red, P.jtol_mult, P.jneg_mult, scal)
+                             : wg_jacobi_cols(p, p, X, ldx, iflag, red, P.jtol_mult, P.jneg_mult, scal);
     if (tid == 0) {
         if (nsw < 0) P.status[b] = 1;
         P.sweep_stats[b] += (nsw < 0 ? -nsw : nsw);
+        if (P.prof && step < 120) P.prof[(long long)P.tt.batch * 8 + (long long)b * 120 + step] = ((long long)p << 32) | (long long)(nsw < 0 ? -nsw : nsw);
     }
 
+    PROF_MARK(3)
     // ---- 5. singular values, sort (descending, stable), rank rule ----
     for (int c = wave; c < p; c += nwaves) {
         double a = 0.0;
-        for (int r = lane; r < p; r += 64) { const double v = X[(long long)c * p + r]; a = fma(v, v, a); }
+        for (int r = lane; r < p; r += 64) { const double v = X[(long long)c * ldx + r]; a = fma(v, v, a); }
         a = wave_sum(a);
         if (lane == 0) sig[c] = sqrt(a);
     }
@@ -411,19 +577,25 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
         for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? sigs[i] * s0 : -1.0;
     }
 
+    PROF_MARK(4)
     // ---- 6. outputs.  left factor (p x r): x_j * sqrt(s0)/sqrt(sig_j) ; right factor (r x q):
     //         (x_j^T M_scaled) * sqrt(s0) / (sig_j*sqrt(sig_j)) ----
     const View Lfv = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));     // (mr x r)
     const View Rfv = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * r});                 // (r x mc)
     const View Lo = wide ? Lfv : tview(Rfv);       // p x r
     const View Ro = wide ? Rfv : tview(Lfv);       // r x q
+    // Columns the Jacobi left alone as numerically zero (norm^2 <= aneg, i.e. sigma_j <= sqrt(m)*eps*sigma_max) are
+    // NOT orthogonal to the dominant directions relative to their own size, so x_j/sigma_j is not a singular
+    // vector; they contribute <= sqrt(m)*eps*sigma_max to M and are written as exact zeros.
     const double sq0 = sqrt(s0);
+    const double aneg = scal[0];
     for (int e = tid; e < p * r; e += TTN_WG) {
         const int row = e % p, j = e / p;
         const double sj = sigs[j];
-        const double xv = X[(long long)perm[j] * p + row];
-        const double lf = (sj > 0.0) ? xv * (sq0 / sqrt(sj)) : 0.0;
-        const double us = (sj > 0.0) ? xv * (sq0 / (sj * sqrt(sj))) : 0.0;
+        const double xv = X[(long long)perm[j] * ldx + row];
+        const bool keep = (sj > 0.0) && (sj * sj > aneg);
+        const double lf = keep ? xv * (sq0 / sqrt(sj)) : 0.0;
+        const double us = keep ? xv * (sq0 / (sj * sqrt(sj))) : 0.0;
         Lo.p[ix(Lo.r, row) + ix(Lo.c, j)] = lf;
         Us[(long long)j * p + row] = us;            // Us^T stored: (r x p) row-major
     }
@@ -431,6 +603,8 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
     wg_gemm(r, q, p, mkview(Us, plain(p), plain(1)), Mv, Ro, 1.0, 0.0, lds);
     if (tid == 0) rks[k + 1] = r;
     __syncthreads();
+    PROF_MARK(5)
+#undef PROF_MARK
 }
 
 __global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {

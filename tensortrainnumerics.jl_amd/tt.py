@@ -197,8 +197,7 @@ def orthogonalize(x_tt: TTvector, i: int = 1) -> TTvector:
     """orthogonalize(x_tt; i=1) — src/tt_tools.jl:511-543 (non-mutating)."""
     d = x_tt.N
     assert 1 <= i <= d, "Impossible orthogonalization"
-    yr0 = r_and_d_to_rks(x_tt.ttv_rks, x_tt.ttv_dims)
-    Y = _empty_cores(x_tt.ttv_dims, yr0)
+    Y = _empty_cores(x_tt.ttv_dims, x_tt.ttv_rks)      # max-size buffers: output ranks never exceed the input's
     Xc = [_f(c) for c in x_tt.ttv_vec]
     yr = (C.c_int64 * (d + 1))()
     yot = (C.c_int64 * d)()

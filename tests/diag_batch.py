@@ -1,0 +1,37 @@
+"""Diagnostic (not a test): run apply+round on a batch of distinct trains, print Jacobi status/sweeps."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ttn_amd as T
+from ttn_amd import device as D
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+d, r = 30, 64
+T.ensure_init(0)
+A = T.Delta(d); dA = T.DeviceTTO(A)
+x0 = T.rand_tt((2,) * d, r, seed=30)
+dx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=B)
+for b in range(B):
+    dx.upload(b, T.rand_tt((2,) * d, r, seed=30 + b))
+dy = T.DeviceTT((2,) * d, [a * c for a, c in zip(A.tto_rks, x0.ttv_rks)], batch=B)
+for it in range(2):
+    D.apply(dA, dx, dy); D.sync()
+    t0 = time.perf_counter()
+    D.tt_compress_(dy, r); D.sync()
+    t1 = time.perf_counter()
+    try:
+        sw = D.compress_status(dy); ok = True
+    except Exception as e:
+        ok = False; print("status:", e)
+        import ctypes as C
+        out = (C.c_int64 * B)(); T._lib.lib().ttn_compress_status(dy.h, out); sw = list(out)
+    print(f"iter {it}: compress {1e3*(t1-t0):.1f} ms  ok={ok} sweeps min/max/mean {min(sw)}/{max(sw)}/{sum(sw)/len(sw):.1f}  -> {B*d/(t1-t0):.0f} cores/s")
+
+if os.environ.get("TTN_PROF"):
+    import ctypes as C
+    out = (C.c_int64 * 8)()
+    T._lib.check(T._lib.lib().ttn_prof_get(0, out))
+    names = ["merge", "scale", "LQ", "jacobi", "sort", "split"]
+    tot = sum(out[:6])
+    print("phase ticks (100MHz):", {n: int(v) for n, v in zip(names, out)}, "total ms", tot / 1e5)
+    st = (C.c_int64 * 120)()
+    T._lib.check(T._lib.lib().ttn_prof_steps(0, st))
+    print("per step (p:sweeps):", " ".join(f"{v >> 32}:{v & 0xffffffff}" for v in st[:2 * (d - 1)]))

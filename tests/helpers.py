@@ -41,10 +41,19 @@ def to_oracle(x):
     return O.TToperator(x.N, [np.array(c) for c in x.tto_vec], tuple(x.tto_dims), list(x.tto_rks), list(x.tto_ot))
 
 
+def tt_norm_stable(x):
+    """||x|| without the cancellation of dot(x,x) on differences: orthogonalize to site 1 (oracle) and take
+    the Frobenius norm of the centre core."""
+    y = O.orthogonalize(x, i=1)
+    return float(np.linalg.norm(y.ttv_vec[0]))
+
+
 def tt_rel_diff(a, b):
-    """||a - b|| / ||b|| through TT inner products (works at d=30 where nothing can be densified)."""
-    aa, bb, ab = O.dot(a, a), O.dot(b, b), O.dot(a, b)
-    return float(np.sqrt(max(aa - 2 * ab + bb, 0.0) / bb))
+    """||a - b|| / ||b|| for trains too long to densify (d=30).  The difference is formed as a TT
+    (ranks add) and its norm taken after orthogonalization, so the result is accurate far below
+    sqrt(eps) (aa - 2ab + bb would cancel catastrophically at ~1e-8)."""
+    diff = O.sub(a, b)
+    return tt_norm_stable(diff) / tt_norm_stable(b)
 
 
 def sign_fix_compare(a, b):

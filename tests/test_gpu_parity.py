@@ -328,9 +328,9 @@ def test_apply_compress_vs_oracle(T, d, r, seed):
     ref = O.tt_compress_(O.apply(O.Delta(d), to_oracle(x)), r, svals_out=sv)
     assert got.ttv_rks == ref.ttv_rks
     for i, s_ref in enumerate(sv):
-        s = dy.singular_values(0, i)
-        assert len(s) == len(s_ref)
-        assert np.allclose(s, s_ref, rtol=1e-10, atol=1e-13 * s_ref[0]), f"bond step {i}"
+        s = dy.singular_values(0, i)            # the device captures ALL singular values, the oracle the kept ones
+        assert len(s) >= len(s_ref)
+        assert np.allclose(s[: len(s_ref)], s_ref, rtol=1e-10, atol=1e-13 * s_ref[0]), f"bond step {i}"
     assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
     assert sign_fix_compare(to_oracle(got), ref) <= 1e-7
 
