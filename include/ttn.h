@@ -90,6 +90,13 @@ int ttn_compress(ttn_tt_t psi, int64_t max_bond, double truncerr, int64_t sweeps
  * total_jacobi_sweeps[b] receives the number of Jacobi sweeps train b used (diagnostics). */
 int ttn_compress_status(ttn_tt_t psi, int64_t* total_jacobi_sweeps);
 
+/* Rank bounds of tt_compress! (k = 0) or one _tt_bond_truncate! (k = 1-based bond).  The reference keeps
+ * r = min(length(s), max_bond) singular values (tt_cross_interpolation.jl:152,164), so the rank of a rank-deficient
+ * bond can GROW up to min(n_k r_{k-1}, n_{k+1} r_{k+1}, max_bond).  need[m] >= rks[m] is the capacity a handle / a
+ * host buffer must have for bond m; fin[m] bounds the ranks after the call.  Either output may be null. */
+int ttn_compress_rank_bound(int64_t d, const int64_t* dims, const int64_t* rks, int64_t max_bond, int64_t sweeps, int64_t k,
+                            int64_t* need, int64_t* fin);
+
 /* _tt_bond_truncate!(psi, k; max_bond, truncerr) without the discarded orthogonalize; k is 1-based */
 int ttn_bond_truncate(ttn_tt_t psi, int64_t k, int64_t max_bond, double truncerr);
 
@@ -125,6 +132,11 @@ int ttn_timer_end(float* ms);   /* synchronises */
 int ttn_event_record(int64_t slot);
 int ttn_event_elapsed(int64_t slot_a, int64_t slot_b, float* ms);
 
+/* kernel unit-test hook: C (m x n row-major, host, in/out) = alpha*op(A)*op(B) + beta*C computed by the device-side
+ * workgroup GEMM (fp64 MFMA) every dense kernel is built on; ta/tb: operand stored transposed */
+int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const double* B, double* C, double alpha, double beta,
+                      int ta, int tb);
+
 /* diagnostic: with TTN_PROF=1 in the environment ttn_compress records s_memtime ticks per phase
  * (merge, scale, LQ, Jacobi, sort/rank, split) for every train; out8 receives train b's 8 counters */
 int ttn_prof_get(int64_t b, int64_t* out8);
@@ -136,8 +148,9 @@ int ttn_prof_steps(int64_t b, int64_t* out120);
  *   apply     : Y_cores[k] sized n_k*(A_rks[k]*X_rks[k])*(A_rks[k+1]*X_rks[k+1])   (as zeros_tt would)
  *   hadamard  : Z_cores[k] sized n_k*(rx*ry)_k*(rx*ry)_{k+1}
  *   add       : Z_cores[k] sized with ranks rx+ry (ends forced to 1)
- *   compress  : in/out cores sized for the INPUT ranks; `rks` is updated in place; cores are rewritten
- *               compactly with the new ranks (the Julia shim re-wraps them to exact-size Arrays)
+ *   compress  : in/out cores sized n_k*need[k]*need[k+1] with need from ttn_compress_rank_bound (= the input
+ *               ranks unless a rank-deficient bond can grow); on entry they hold the input cores compactly,
+ *               on exit the new cores compactly; `rks` is updated in place
  *   orthogonalize: Y_cores sized for X_rks (output ranks never exceed the input's) ; Y_rks / Y_ot are outputs
  */
 int ttn_apply_f64(int64_t d, const int64_t* dims,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "ttn_apply": (C.c_int, [handle, handle, handle]),
     "ttn_compress": (C.c_int, [handle, i64, C.c_double, i64]),
     "ttn_compress_status": (C.c_int, [handle, p_i64]),
+    "ttn_compress_rank_bound": (C.c_int, [i64, p_i64, p_i64, i64, i64, i64, p_i64, p_i64]),
     "ttn_bond_truncate": (C.c_int, [handle, i64, i64, C.c_double]),
     "ttn_apply_compress": (C.c_int, [handle, handle, handle, i64, C.c_double, i64]),
     "ttn_dot": (C.c_int, [handle, handle, p_f64]),
@@ -66,6 +67,7 @@ SIGNATURES = {
     "ttn_sv_get": (C.c_int, [handle, i64, i64, p_f64, i64, p_i64]),
     "ttn_timer_begin": (C.c_int, []),
     "ttn_timer_end": (C.c_int, [C.POINTER(C.c_float)]),
+    "ttn_selftest_gemm": (C.c_int, [i64, i64, i64, p_f64, p_f64, p_f64, C.c_double, C.c_double, C.c_int, C.c_int]),
     "ttn_prof_get": (C.c_int, [i64, p_i64]),
     "ttn_prof_steps": (C.c_int, [i64, p_i64]),
     "ttn_event_record": (C.c_int, [i64]),

@@ -531,18 +531,50 @@ int ttn_scale(double a, ttn_tt_t x, ttn_tt_t y) {
 }
 
 // ---- dense ops ------------------------------------------------------------------------------------
+// Upper bounds on the ranks during / after tt_compress! (or one _tt_bond_truncate!).  The reference sets
+// r = min(length(s), max_bond) with length(s) = min(n_k r_{k-1}, n_{k+1} r_{k+1}) (tt_cross_interpolation.jl:152,164),
+// so a bond rank can GROW when it was below both of those (rank-deficient input).  need[m] = largest rank bond m can
+// take at any time (buffers / handle capacity must hold it), fin[m] = bound after the call.
+static void rank_bounds(int d, const int64_t* dims, const int64_t* rks, int64_t max_bond, int64_t sweeps, int64_t k_single,
+                        std::vector<int64_t>& need, std::vector<int64_t>& fin, long long& pmax, long long& qmax) {
+    fin.assign(rks, rks + d + 1);
+    need = fin;
+    pmax = 1; qmax = 1;
+    auto stepk = [&](int k) {      // 0-based bond between cores k, k+1
+        const long long mr = dims[k] * fin[k], mc = dims[k + 1] * fin[k + 2];
+        const long long p = std::min(mr, mc), q = std::max(mr, mc);
+        pmax = std::max(pmax, p); qmax = std::max(qmax, q);
+        fin[k + 1] = std::min<long long>(p, max_bond);
+        need[k + 1] = std::max(need[k + 1], fin[k + 1]);
+    };
+    if (k_single > 0) { stepk((int)k_single - 1); return; }
+    for (int64_t sw = 0; sw < sweeps; ++sw) {
+        for (int k = 0; k + 1 < d; ++k) stepk(k);
+        for (int k = d - 2; k >= 0; --k) stepk(k);
+    }
+}
+
+int ttn_compress_rank_bound(int64_t d, const int64_t* dims, const int64_t* rks, int64_t max_bond, int64_t sweeps, int64_t k,
+                            int64_t* need_out, int64_t* final_out) {
+    if (!dims || !rks || d < 1 || max_bond < 1 || sweeps < 1 || k < 0 || k > d - 1)
+        return fail(TTN_ERR_ARG, "bad argument");
+    std::vector<int64_t> need, fin;
+    long long pm, qm;
+    rank_bounds((int)d, dims, rks, max_bond, sweeps, k, need, fin, pm, qm);
+    for (int64_t m = 0; m <= d; ++m) { if (need_out) need_out[m] = need[m]; if (final_out) final_out[m] = fin[m]; }
+    return TTN_OK;
+}
+
 static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, double truncerr, int64_t sweeps) {
     const int d = psi->d;
     if (d < 2 && k_single == 0) return TTN_OK;
-    // bounds on merged-matrix sides from the host rank bounds
+    std::vector<int64_t> need, fin;
     long long pmax = 1, qmax = 1;
-    for (int k = 0; k + 1 < d; ++k) {
-        const long long mr = psi->dims[k] * psi->bound[k], mc = psi->dims[k + 1] * psi->bound[k + 2];
-        pmax = std::max(pmax, std::min(mr, mc));
-        qmax = std::max(qmax, std::max(mr, mc));
-    }
+    rank_bounds(d, psi->dims.data(), psi->bound.data(), max_bond, sweeps, k_single, need, fin, pmax, qmax);
+    for (int m = 0; m <= d; ++m)
+        if (need[m] > psi->cap[m]) return fail(TTN_ERR_CAPACITY, "ttn_compress: a bond rank can grow beyond the handle's capacity (see ttn_compress_rank_bound)");
     if (pmax > 4096 || qmax > 16384) return fail(TTN_ERR_UNSUPPORTED, "ttn_compress: merged matrix larger than 4096 x 16384");
-    const long long per_train = 2 * pmax * qmax + QR_NB * qmax + pmax * QR_NB + 2 * pmax * pmax + 4 * pmax + 64;
+    const long long per_train = 2 * pmax * qmax + QR_NB * qmax + pmax * QR_NB + 2 * pmax * pmax + 4 * pmax + 64 + 6 * 128 * 128;
     int rc = ensure_scratch(sizeof(double) * (size_t)per_train * psi->batch);
     if (rc) return rc;
     rc = ensure_batch_bufs(psi->batch);
@@ -579,14 +611,10 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     }
     { const char* e = getenv("TTN_JTOL"); P.jtol_mult = e ? atof(e) : 1.0; }
     { const char* e = getenv("TTN_JNEG"); P.jneg_mult = e ? atof(e) : 1.0; }
+    { const char* e = getenv("TTN_FAST"); P.fast = e ? atoi(e) : 1; }
     hipLaunchKernelGGL(k_compress, dim3(psi->batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, P);
     HIPCHK(hipGetLastError());
-    // host rank bounds after truncation
-    if (k_single) {
-        psi->bound[k_single] = std::min<int64_t>(psi->bound[k_single], max_bond);
-    } else {
-        for (int m = 1; m < d; ++m) psi->bound[m] = std::min<int64_t>(psi->bound[m], max_bond);
-    }
+    psi->bound = fin;
     return TTN_OK;
 }
 
@@ -681,7 +709,7 @@ int ttn_dot(ttn_tt_t a, ttn_tt_t b, double* out) {
     P.scratch = (double*)g_scratch; P.scratch_stride = per_train;
     P.ramax = (int)ramax; P.rbmax = (int)rbmax; P.nmax = (int)nmax;
     P.out = g_dout;
-    hipLaunchKernelGGL(k_dot, dim3(a->batch), dim3(TTN_WG), sizeof(double) * GEMM_LDS_DOUBLES, g_stream, P);
+    hipLaunchKernelGGL(k_dot, dim3(a->batch), dim3(TTN_WG), sizeof(double) * GEMM_LDS_TOTAL, g_stream, P);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, g_dout, sizeof(double) * a->batch, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
@@ -727,6 +755,28 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     y->bound = yb;
     for (int b = 0; b < y->batch; ++b)
         for (int k = 0; k < d; ++k) y->ot[(size_t)b * d + k] = (k < center - 1) ? 1 : (k > center - 1 ? -1 : 0);
+    return TTN_OK;
+}
+
+// kernel unit-test hook: C (m x n, row-major, host) = alpha * op(A) * op(B) + beta * C through wg_gemm on the device
+int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const double* B, double* C, double alpha, double beta,
+                      int ta, int tb) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!A || !B || !C || m < 1 || n < 1 || k < 1) return fail(TTN_ERR_ARG, "bad argument");
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    HIPCHK(hipMalloc((void**)&dA, sizeof(double) * m * k));
+    HIPCHK(hipMalloc((void**)&dB, sizeof(double) * k * n));
+    HIPCHK(hipMalloc((void**)&dC, sizeof(double) * m * n));
+    HIPCHK(hipMemcpyAsync(dA, A, sizeof(double) * m * k, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(dB, B, sizeof(double) * k * n, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(dC, C, sizeof(double) * m * n, hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(k_selftest_gemm, dim3(1), dim3(TTN_WG), sizeof(double) * GEMM_LDS_TOTAL, g_stream, (int)m, (int)n, (int)k,
+                       dA, dB, dC, alpha, beta, ta, tb);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(C, dC, sizeof(double) * m * n, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    hipFree(dA); hipFree(dB); hipFree(dC);
     return TTN_OK;
 }
 
@@ -864,7 +914,11 @@ static int compress_host(int64_t d, const int64_t* dims, double* const* cores, i
     int rc = auto_init(); if (rc) return rc;
     if (!dims || !cores || !rks || d < 1) return fail(TTN_ERR_ARG, "bad argument");
     TmpTT x;
-    if ((rc = ttn_tt_create(d, dims, rks, 1, &x.h))) return rc;
+    if (max_bond < 1) return fail(TTN_ERR_ARG, "max_bond must be >= 1");
+    std::vector<int64_t> need, fin;
+    long long pm, qm;
+    rank_bounds((int)d, dims, rks, max_bond, sweeps, k, need, fin, pm, qm);
+    if ((rc = ttn_tt_create(d, dims, need.data(), 1, &x.h))) return rc;
     if ((rc = ttn_tt_upload(x.h, 0, cores, rks, nullptr))) return rc;
     if (k > 0) rc = ttn_bond_truncate(x.h, k, max_bond, truncerr);
     else rc = ttn_compress(x.h, max_bond, truncerr, sweeps);

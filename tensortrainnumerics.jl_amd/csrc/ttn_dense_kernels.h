@@ -13,7 +13,7 @@
 #define GEMM_BM 128
 #define GEMM_BN 128
 #define GEMM_BK 16
-#define GEMM_LD 132                      // padded LDS leading dimension (doubles)
+#define GEMM_LD 144                      // LDS leading dimension (doubles): 144 % 32 == 16 spreads a half-wave's two k-rows over all banks
 #define GEMM_LDS_DOUBLES (2 * GEMM_BK * GEMM_LD)
 #define QR_NB 16                         // Householder panel width
 #define JACOBI_MAX_SWEEPS 40
@@ -55,70 +55,133 @@ __device__ inline double wg_max(double v, double* red) {
 
 // -------------------------------------------------------------------------------------------------
 // wg_gemm: C[m x n] = alpha * A[m x k] * B[k x n] + beta * C, all operands through Views.
-// 128x128x16 LDS tiles, 4x4 register micro-tile per thread (1024 threads), fp64 FMA.
+// fp64 MFMA (v_mfma_f64_16x16x4_f64): the 16 waves form a 4x4 grid, each wave owns a 32x32 block of a
+// 128x128 output tile (2x2 MFMA tiles, 16 accumulator doubles per lane).  K is consumed in chunks of
+// 16 staged through LDS (k-major, leading dimension 144 doubles so the two 16-lane k-rows a half-wave
+// reads land on disjoint bank halves); the next chunk's global loads are issued before the MFMAs of
+// the current one.  Fragment maps (one f64 per lane): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], D[row = (lane>>4) + 4*reg][col = lane&15].
 // Every thread of the workgroup must call it (it contains barriers).
 // -------------------------------------------------------------------------------------------------
-__device__ void wg_gemm(int m, int n, int k, View A, View B, View C, double alpha, double beta, double* lds) {
-    const int tid = threadIdx.x;
-    const int tx = tid & 31, ty = tid >> 5;
-    double* As = lds;
-    double* Bs = lds + GEMM_BK * GEMM_LD;
-    // which index runs fastest across consecutive threads when staging (pick the smaller stride)
+typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) double lds_f64;
+
+struct GemmDesc {
+    int m, n, k, pad;
+    View A, B, C;
+    double alpha, beta;
+};
+#define GEMM_DESC_DOUBLES 32            // sizeof(GemmDesc) = 200 bytes, kept right behind the LDS tiles
+#define GEMM_LDS_TOTAL (GEMM_LDS_DOUBLES + GEMM_DESC_DOUBLES)
+
+// The body is deliberately NOT inlined (17 call sites) and takes its operands through a descriptor in LDS: only two
+// pointers cross the call boundary.
+__device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
+    const int m = dsc->m, n = dsc->n, k = dsc->k;
+    const View A = dsc->A, B = dsc->B, C = dsc->C;
+    const double alpha = dsc->alpha, beta = dsc->beta;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int li = lane & 15, lk = lane >> 4;
+    lds_f64* As = (lds_f64*)lds;
+    lds_f64* Bs = As + GEMM_BK * GEMM_LD;
     const bool a_kfast = minstride(A.c) < minstride(A.r);
     const bool b_kfast = minstride(B.r) < minstride(B.c);
+    // staging assignment: element e = tid + 1024*u, u = 0,1 of the 128x16 (A) and 16x128 (B) chunk
+    int ar[2], akk[2], bc[2], bkk[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + TTN_WG * u;
+        if (a_kfast) { akk[u] = e & (GEMM_BK - 1); ar[u] = e >> 4; } else { ar[u] = e & (GEMM_BM - 1); akk[u] = e >> 7; }
+        if (b_kfast) { bkk[u] = e & (GEMM_BK - 1); bc[u] = e >> 4; } else { bc[u] = e & (GEMM_BN - 1); bkk[u] = e >> 7; }
+    }
     for (int m0 = 0; m0 < m; m0 += GEMM_BM) {
         for (int n0 = 0; n0 < n; n0 += GEMM_BN) {
-            double acc[4][4];
+            long long aoff[2], boff[2];
+            bool aok[2], bok[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int u = 0; u < 2; ++u) {
+                aok[u] = (m0 + ar[u]) < m;
+                bok[u] = (n0 + bc[u]) < n;
+                aoff[u] = aok[u] ? ix(A.r, m0 + ar[u]) : 0;
+                boff[u] = bok[u] ? ix(B.c, n0 + bc[u]) : 0;
+            }
+            const bool live = (m0 + wr * 32 < m) && (n0 + wc * 32 < n);      // wave-uniform
+            mfma_acc_t acc[2][2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+            double av[2], bv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                av[u] = (aok[u] && akk[u] < k) ? A.p[aoff[u] + ix(A.c, akk[u])] : 0.0;
+                bv[u] = (bok[u] && bkk[u] < k) ? B.p[boff[u] + ix(B.r, bkk[u])] : 0.0;
+            }
             for (int k0 = 0; k0 < k; k0 += GEMM_BK) {
-                __syncthreads();
-                for (int e = tid; e < GEMM_BM * GEMM_BK; e += TTN_WG) {
-                    int r, kk;
-                    if (a_kfast) { kk = e & (GEMM_BK - 1); r = e >> 4; } else { r = e & (GEMM_BM - 1); kk = e >> 7; }
-                    const int gi = m0 + r, gk = k0 + kk;
-                    As[kk * GEMM_LD + r] = (gi < m && gk < k) ? A.p[ix(A.r, gi) + ix(A.c, gk)] : 0.0;
-                }
-                for (int e = tid; e < GEMM_BN * GEMM_BK; e += TTN_WG) {
-                    int c, kk;
-                    if (b_kfast) { kk = e & (GEMM_BK - 1); c = e >> 4; } else { c = e & (GEMM_BN - 1); kk = e >> 7; }
-                    const int gj = n0 + c, gk = k0 + kk;
-                    Bs[kk * GEMM_LD + c] = (gj < n && gk < k) ? B.p[ix(B.r, gk) + ix(B.c, gj)] : 0.0;
+                __syncthreads();                       // the previous chunk has been consumed
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    As[akk[u] * GEMM_LD + ar[u]] = av[u];
+                    Bs[bkk[u] * GEMM_LD + bc[u]] = bv[u];
                 }
                 __syncthreads();
+                const int k1 = k0 + GEMM_BK;
+                if (k1 < k) {
 #pragma unroll
-                for (int kk = 0; kk < GEMM_BK; ++kk) {
-                    double a[4], b[4];
+                    for (int u = 0; u < 2; ++u) {
+                        const int ga = k1 + akk[u], gb = k1 + bkk[u];
+                        av[u] = (aok[u] && ga < k) ? A.p[aoff[u] + ix(A.c, ga)] : 0.0;
+                        bv[u] = (bok[u] && gb < k) ? B.p[boff[u] + ix(B.r, gb)] : 0.0;
+                    }
+                }
+                if (live) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = As[kk * GEMM_LD + ty * 4 + i];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) b[j] = Bs[kk * GEMM_LD + tx * 4 + j];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+                    for (int t = 0; t < GEMM_BK / 4; ++t) {
+                        const int kr = (4 * t + lk) * GEMM_LD;
+                        const double a0 = As[kr + wr * 32 + li], a1 = As[kr + wr * 32 + 16 + li];
+                        const double b0 = Bs[kr + wc * 32 + li], b1 = Bs[kr + wc * 32 + 16 + li];
+                        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                    }
                 }
             }
+            if (live) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gi = m0 + ty * 4 + i;
-                if (gi >= m) continue;
-                const long long ro = ix(C.r, gi);
+                for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int gj = n0 + tx * 4 + j;
-                    if (gj >= n) continue;
-                    double* cp = C.p + ro + ix(C.c, gj);
-                    double v = alpha * acc[i][j];
-                    if (beta != 0.0) v += beta * (*cp);
-                    *cp = v;
-                }
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int gi = m0 + wr * 32 + ti * 16 + lk + 4 * reg;
+                        if (gi >= m) continue;
+                        const long long ro = ix(C.r, gi);
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj) {
+                            const int gj = n0 + wc * 32 + tj * 16 + li;
+                            if (gj >= n) continue;
+                            double* cp = C.p + ro + ix(C.c, gj);
+                            double v = alpha * acc[ti][tj][reg];
+                            if (beta != 0.0) v += beta * (*cp);
+                            *cp = v;
+                        }
+                    }
             }
         }
     }
     __syncthreads();
+}
+
+__device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, double alpha, double beta, double* lds) {
+    GemmDesc* dsc = reinterpret_cast<GemmDesc*>(lds + GEMM_LDS_DOUBLES);
+    __syncthreads();                         // nobody still reads what the tiles / descriptor alias
+    if (threadIdx.x == 0) {
+        dsc->m = m; dsc->n = n; dsc->k = k; dsc->pad = 0;
+        dsc->A = A; dsc->B = B; dsc->C = C;
+        dsc->alpha = alpha; dsc->beta = beta;
+    }
+    __syncthreads();
+    wg_gemm_impl(dsc, lds);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -299,8 +362,6 @@ __device__ __noinline__ int wg_jacobi_cols(int m, int p, double* X, int ldx, int
 //     (it sets the speed of convergence), c = rsqrt(1+t^2) gets two Newton steps so that c^2+s^2 = 1
 //     to rounding (that is what makes every applied rotation orthogonal, i.e. backward stable).
 // -------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) double lds_f64;
-
 template <int CTRL>
 __device__ inline double dpp_mov_f64(double v) {
     union { double d; int i[2]; } a, r;
@@ -428,6 +489,42 @@ __device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* n
 }
 
 // -------------------------------------------------------------------------------------------------
+// Cholesky G = L L^T in LDS (column-major, leading dimension 128, n <= 128), in place: on exit the lower
+// triangle holds L and the strict upper triangle is zeroed.  Returns 0, or 1 if a pivot is not safely
+// positive (d_j <= n*eps*max_diag): the caller then falls back to the Householder path.
+// -------------------------------------------------------------------------------------------------
+__device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* flag) {
+    const int tid = threadIdx.x;
+    lds_f64* G = (lds_f64*)Gg;
+    double dmax = 0.0;
+    for (int j = tid; j < n; j += TTN_WG) dmax = fmax(dmax, G[j * 128 + j]);
+    dmax = wg_max(dmax, red);
+    const double dmin = (double)n * DBL_EPSILON * dmax;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double d = G[j * 128 + j];
+        if (!(d > dmin)) { if (tid == 0) *flag = 1; break; }       // uniform: every thread reads the same d
+        const double inv = 1.0 / sqrt(d);
+        __syncthreads();
+        for (int i = j + tid; i < n; i += TTN_WG) G[j * 128 + i] *= inv;        // column j (incl. diagonal -> sqrt(d))
+        __syncthreads();
+        // trailing update: G[i][c] -= L[i][j]*L[c][j] for j < c <= i   (column c, rows c..n-1)
+        const int nt = n - j - 1;
+        for (int e = tid; e < nt * nt; e += TTN_WG) {
+            const int c = j + 1 + e / nt, i = j + 1 + e % nt;
+            if (i >= c) G[c * 128 + i] = fma(-G[j * 128 + i], G[j * 128 + c], G[c * 128 + i]);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int bad = *flag;
+    for (int e = tid; e < n * n; e += TTN_WG) { const int c = e / n, i = e % n; if (i < c) G[c * 128 + i] = 0.0; }
+    __syncthreads();
+    return bad;
+}
+
+// -------------------------------------------------------------------------------------------------
 // Parameters of the compress / bond-truncate kernel
 // -------------------------------------------------------------------------------------------------
 struct CompressArgs {
@@ -444,17 +541,99 @@ struct CompressArgs {
     int* status;           // [batch] device: 0 ok, 1 = Jacobi did not converge
     int* sweep_stats;      // [batch] device: total Jacobi sweeps (diagnostics)
     double jtol_mult;      // Jacobi convergence threshold = jtol_mult * sqrt(m) * eps
-    long long* prof;       // null, or [batch][8] cycle counters per phase (diagnostic builds of the launch only)
+    long long* prof;       // null, or cycle counters per phase (TTN_PROF=1 diagnostic launches only)
     double jneg_mult;      // columns below jneg_mult * sqrt(m) * eps * max column norm are treated as zero
+    int fast;              // 1: try the Gram/Cholesky fast paths (verified a posteriori) before Householder
 };
 
 #define COMPRESS_LDS_X_DOUBLES (128 * 128)
 #define COMPRESS_LDS_BYTES ((COMPRESS_LDS_X_DOUBLES + 32 + 2 * QR_NB * QR_NB + QR_NB + 8 + 8 + 128) * sizeof(double))
+#define FAST_KAPPA_MAX 128.0          // fast paths are used only when sigma_max/sigma_min <= this (error ~ eps*kappa^2)
+#define FAST_CHECK_TOL 2.0e-11        // a-posteriori bound on |Rf Rf^T - Sigma| (and Lf^T Lf - Sigma), relative
+
+struct BondCtx {
+    // LDS
+    double *ldsX, *red, *Ts, *Ss, *taus, *scal, *nrm2;
+    int* iflag;
+    // global scratch
+    double *M, *M2, *Vb, *Wb, *Us, *Xg, *sig, *sigs, *Ga, *Gb, *Cc, *T1, *T2, *T3;
+    int* perm;
+};
+
+// Jacobi on the pj columns (length pj) of X, then singular values sigma_c = ||x_c|| sorted descending with a
+// stable order: perm[pos] = column, sigs[pos] = sigma (scaled units).  Returns the sweep count (<0: limit hit).
+__device__ int wg_svd_cols(const CompressArgs& P, const BondCtx& S, int pj, double* X, int ldx, bool in_lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    const int nsw = in_lds ? wg_jacobi_lds128(pj, pj, X, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
+                           : wg_jacobi_cols(pj, pj, X, ldx, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal);
+    for (int c = wave; c < pj; c += nwaves) {
+        double a = 0.0;
+        for (int r = lane; r < pj; r += 64) { const double v = X[(long long)c * ldx + r]; a = fma(v, v, a); }
+        a = wave_sum(a);
+        if (lane == 0) S.sig[c] = sqrt(a);
+    }
+    __syncthreads();
+    for (int c = tid; c < pj; c += TTN_WG) {
+        const double sc = S.sig[c];
+        int pos = 0;
+        for (int j = 0; j < pj; ++j) { const double sj = S.sig[j]; pos += (sj > sc) || (sj == sc && j < c); }
+        S.perm[pos] = c;
+        S.sigs[pos] = sc;
+    }
+    __syncthreads();
+    return nsw;
+}
+
+// The effective _svdtrunc rank rule (src/tt_cross_interpolation.jl:149-166) on `ns` computed singular values
+// (scaled by s0) padded with zeros to the reference's length `plen` = min(size(M)).  All threads get r.
+__device__ int wg_rank_rule(const CompressArgs& P, const BondCtx& S, int ns, int plen, double s0) {
+    if (threadIdx.x == 0) {
+        int r = plen;
+        if (P.truncerr > 0.0) {
+            double n2 = 0.0;
+            for (int i = 0; i < ns; ++i) { const double s = S.sigs[i] * s0; n2 = fma(s, s, n2); }
+            const double nrm = sqrt(n2);
+            double cum = 0.0;
+            for (int i = plen; i >= 1; --i) {
+                const double s = (i <= ns) ? S.sigs[i - 1] * s0 : 0.0;
+                cum = fma(s, s, cum);
+                if (sqrt(cum) > P.truncerr * nrm) { r = i; break; }
+            }
+        }
+        if ((long long)r > P.max_bond) r = (int)P.max_bond;
+        S.iflag[1] = r;
+    }
+    __syncthreads();
+    const int r = S.iflag[1];
+    __syncthreads();
+    return r;
+}
+
+// max over i,j < r of |D[i + ldd*j] - delta_ij * sigs[i]*s0| / (s0*sqrt(sigs[i]*sigs[j]))
+__device__ double wg_check_diag(const BondCtx& S, const double* D, int ldd, int r, double s0) {
+    double worst = 0.0;
+    for (int e = threadIdx.x; e < r * r; e += TTN_WG) {
+        const int i = e % r, j = e / r;
+        const double si = S.sigs[i], sj = S.sigs[j];
+        const double ref = (i == j) ? si * s0 : 0.0;
+        worst = fmax(worst, fabs(D[i + (long long)ldd * j] - ref) / (s0 * sqrt(si * sj)));
+    }
+    return wg_max(worst, S.red);
+}
 
 // One bond step on (core_k, core_{k+1}), 0-based k.  src/tt_tools.jl:743-768 with the effective
 // _svdtrunc of src/tt_cross_interpolation.jl:149-166.
+//
+// With A' (p x rm), B' (rm x q) the two cores viewed as matrices (transposed roles when the merged matrix
+// is tall) and M = A'B' (p <= q), three numerically distinct routes produce U sqrt(S) and sqrt(S) V^T:
+//   F  (rm < p)  factored: Cholesky of A'^T A' and B' B'^T, Jacobi SVD of the rm x rm core L_A^T L_B,
+//                outputs by small GEMMs; never forms M.                     [R->L steps of a sweep]
+//   G  (q > p)   Gram: L = chol(M M^T), Jacobi on the columns of L.         [L->R steps]
+//   H            robust: blocked Householder LQ of M (or M itself if square), Jacobi on its columns.
+// F and G square the condition number, so they are taken only if sigma_max/sigma_min <= FAST_KAPPA_MAX and are
+// verified a posteriori (Rf Rf^T = Sigma, Lf^T Lf = Sigma to FAST_CHECK_TOL); otherwise the step is redone by H.
 __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, double* lds) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    const int tid = threadIdx.x;
     const TTDev& T = P.tt;
     long long* rks = T.rks + (long long)b * (T.d + 1);
     const int n1 = T.dims[k], n2 = T.dims[k + 1];
@@ -470,140 +649,243 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
     const View Ap = wide ? Am : tview(Bm);       // p x rm
     const View Bp = wide ? Bm : tview(Am);       // rm x q
 
-    // ---- LDS carve-up ----
-    double* ldsX = lds;                                   // COMPRESS_LDS_X_DOUBLES (aliases the GEMM tiles)
-    double* red = lds + COMPRESS_LDS_X_DOUBLES;           // 32
-    double* Ts = red + 32;                                // QR_NB*QR_NB
-    double* Ss = Ts + QR_NB * QR_NB;                      // QR_NB*QR_NB
-    double* taus = Ss + QR_NB * QR_NB;                    // QR_NB
-    double* scal = taus + QR_NB;                          // 8 misc doubles
-    int* iflag = reinterpret_cast<int*>(scal + 8);        // 8 ints
-    double* nrm2 = scal + 16;                             // 128 cached squared column norms
-    // ---- global scratch carve-up ----
+    BondCtx S;
+    S.ldsX = lds;                                         // COMPRESS_LDS_X_DOUBLES (aliases the GEMM tiles)
+    S.red = lds + COMPRESS_LDS_X_DOUBLES;                 // 32
+    S.Ts = S.red + 32;                                    // QR_NB*QR_NB
+    S.Ss = S.Ts + QR_NB * QR_NB;                          // QR_NB*QR_NB
+    S.taus = S.Ss + QR_NB * QR_NB;                        // QR_NB
+    S.scal = S.taus + QR_NB;                              // 8 misc doubles (scal[0] = Jacobi's negligible threshold)
+    S.iflag = reinterpret_cast<int*>(S.scal + 8);         // 8 ints
+    S.nrm2 = S.scal + 16;                                 // 128 cached squared column norms
     double* scr = P.scratch + (long long)b * P.scratch_stride;
     const long long pq = (long long)P.pmax * P.qmax;
-    double* M = scr;                                      // p x q row-major
-    double* M2 = M + pq;                                  // copy for LQ
-    double* Vb = M2 + pq;                                 // QR_NB x qmax
-    double* Wb = Vb + (long long)QR_NB * P.qmax;          // pmax x QR_NB
-    double* Us = Wb + (long long)P.pmax * QR_NB;          // pmax x pmax (scaled, sorted left vectors)
-    double* Xg = Us + (long long)P.pmax * P.pmax;         // pmax x pmax Jacobi fallback when LDS is too small
-    double* sig = Xg + (long long)P.pmax * P.pmax;        // pmax singular values (unsorted)
-    double* sigs = sig + P.pmax;                          // pmax sorted
-    int* perm = reinterpret_cast<int*>(sigs + P.pmax);    // pmax ints: sorted position -> column
+    S.M = scr;                                            // p x q row-major
+    S.M2 = S.M + pq;                                      // copy for LQ (F path: Lf/Rf staging uses M..M2)
+    S.Vb = S.M2 + pq;                                     // QR_NB x qmax
+    S.Wb = S.Vb + (long long)QR_NB * P.qmax;              // pmax x QR_NB
+    S.Us = S.Wb + (long long)P.pmax * QR_NB;              // pmax x pmax
+    S.Xg = S.Us + (long long)P.pmax * P.pmax;             // pmax x pmax Jacobi fallback when LDS is too small
+    S.sig = S.Xg + (long long)P.pmax * P.pmax;            // pmax
+    S.sigs = S.sig + P.pmax;                              // pmax
+    S.perm = reinterpret_cast<int*>(S.sigs + P.pmax);     // pmax ints
+    S.Ga = S.sigs + 2 * P.pmax;                           // 6 x (128 x 128) fast-path matrices
+    S.Gb = S.Ga + 128 * 128;
+    S.Cc = S.Gb + 128 * 128;
+    S.T1 = S.Cc + 128 * 128;
+    S.T2 = S.T1 + 128 * 128;
+    S.T3 = S.T2 + 128 * 128;
 
     long long t_prev = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define PROF_MARK(slot) if (P.prof) { __syncthreads(); if (tid == 0) { long long t_now = (long long)__builtin_amdgcn_s_memtime(); P.prof[(long long)b * 8 + (slot)] += t_now - t_prev; t_prev = t_now; } }
-    // ---- 1. merge: M = A' * B'  (p x q) ----
-    const View Mv = mkview(M, plain(q), plain(1));
-    wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds);
 
-    PROF_MARK(0)
-    // ---- 2. scale to max|M| = 1 (guards the squared norms in Jacobi against over/underflow) ----
-    double mx = 0.0;
-    for (long long e = tid; e < (long long)p * q; e += TTN_WG) mx = fmax(mx, fabs(M[e]));
-    mx = wg_max(mx, red);
-    const double s0 = (mx > 0.0) ? mx : 1.0;
-    const double inv_s0 = 1.0 / s0;
-    const bool need_lq = q > p;
-    for (long long e = tid; e < (long long)p * q; e += TTN_WG) {
-        const double v = M[e] * inv_s0;
-        M[e] = v;
-        if (need_lq) M2[e] = v;
-    }
-    __syncthreads();
+    const View Lfv = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));     // (mr x r)
+    int route = 2;                                        // 0 = F, 1 = G, 2 = H (for the diagnostics)
+    int nsw_total = 0;
+    bool done = false;
 
-    PROF_MARK(1)
-    // ---- 3. triangular factor: L (p x p) with M = L Q ----
-    if (need_lq) wg_lq_factor(p, q, M2, q, Vb, Wb, lds, Ts, Ss, taus, red);
-
-    PROF_MARK(2)
-    // ---- 4. Jacobi on the columns of L (or of M itself when square) ----
-    const bool x_in_lds = p <= 128;                       // fast path: X in LDS with leading dimension 128
-    double* X = x_in_lds ? ldsX : Xg;
-    const int ldx = x_in_lds ? 128 : p;
-    const double* Lsrc = need_lq ? M2 : M;               // row-major, ld = q
-    for (int e = tid; e < p * p; e += TTN_WG) {
-        const int r = e % p, c = e / p;                   // X[r + ldx*c] = L[r][c]
-        const double v = Lsrc[(long long)r * q + c];
-        X[(long long)c * ldx + r] = (need_lq && c > r) ? 0.0 : v;
-    }
-    __syncthreads();
-    const int nsw = (x_in_lds && P.jneg_mult < 100.0) ? wg_jacobi_lds128(p, p, X, nrm2, iflag, red, P.jtol_mult, P.jneg_mult, scal)
-                             : wg_jacobi_cols(p, p, X, ldx, iflag, red, P.jtol_mult, P.jneg_mult, scal);
-    if (tid == 0) {
-        if (nsw < 0) P.status[b] = 1;
-        P.sweep_stats[b] += (nsw < 0 ? -nsw : nsw);
-        if (P.prof && step < 120) P.prof[(long long)P.tt.batch * 8 + (long long)b * 120 + step] = ((long long)p << 32) | (long long)(nsw < 0 ? -nsw : nsw);
-    }
-
-    PROF_MARK(3)
-    // ---- 5. singular values, sort (descending, stable), rank rule ----
-    for (int c = wave; c < p; c += nwaves) {
-        double a = 0.0;
-        for (int r = lane; r < p; r += 64) { const double v = X[(long long)c * ldx + r]; a = fma(v, v, a); }
-        a = wave_sum(a);
-        if (lane == 0) sig[c] = sqrt(a);
-    }
-    __syncthreads();
-    for (int c = tid; c < p; c += TTN_WG) {
-        const double sc = sig[c];
-        int pos = 0;
-        for (int j = 0; j < p; ++j) { const double sj = sig[j]; pos += (sj > sc) || (sj == sc && j < c); }
-        perm[pos] = c;
-        sigs[pos] = sc;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int r = p;
-        if (P.truncerr > 0.0) {
-            double nrm2 = 0.0;
-            for (int i = 0; i < p; ++i) { const double s = sigs[i] * s0; nrm2 = fma(s, s, nrm2); }
-            const double nrm = sqrt(nrm2);
-            double cum = 0.0;
-            for (int i = p; i >= 1; --i) {
-                const double s = sigs[i - 1] * s0;
-                cum = fma(s, s, cum);
-                if (sqrt(cum) > P.truncerr * nrm) { r = i; break; }
+    // =============================== route F: factored ===============================
+    if (P.fast && rm < p && rm <= 128 && rm >= 2) {
+        // scales
+        double sa = 0.0, sb = 0.0;
+        for (long long e = tid; e < (long long)n1 * Dl * rm; e += TTN_WG) sa = fmax(sa, fabs(ck[e]));
+        for (long long e = tid; e < (long long)n2 * rm * Dr; e += TTN_WG) sb = fmax(sb, fabs(ck1[e]));
+        sa = wg_max(sa, S.red);
+        sb = wg_max(sb, S.red);
+        bool ok = (sa > 0.0) && (sb > 0.0);
+        const double sA = wide ? sa : sb, sB = wide ? sb : sa;       // scale of A', B'
+        const double s0 = sA * sB;
+        const View Gav = mkview(S.Ga, plain(1), plain(128));
+        const View Gbv = mkview(S.Gb, plain(1), plain(128));
+        const View Ccv = mkview(S.Cc, plain(1), plain(128));
+        const View Xlv = mkview(S.ldsX, plain(1), plain(128));
+        if (ok) {
+            wg_gemm(rm, rm, p, tview(Ap), Ap, Gav, 1.0 / (sA * sA), 0.0, lds);          // A'^T A'
+            wg_gemm(rm, rm, q, Bp, tview(Bp), Gbv, 1.0 / (sB * sB), 0.0, lds);          // B' B'^T
+            // L_A
+            for (int e = tid; e < rm * rm; e += TTN_WG) S.ldsX[(e / rm) * 128 + e % rm] = S.Ga[(e / rm) * 128 + e % rm];
+            __syncthreads();
+            ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag) == 0;
+            for (int e = tid; e < rm * rm; e += TTN_WG) S.Ga[(e / rm) * 128 + e % rm] = S.ldsX[(e / rm) * 128 + e % rm];
+            __syncthreads();
+        }
+        if (ok) {
+            for (int e = tid; e < rm * rm; e += TTN_WG) S.ldsX[(e / rm) * 128 + e % rm] = S.Gb[(e / rm) * 128 + e % rm];
+            __syncthreads();
+            ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag) == 0;
+            for (int e = tid; e < rm * rm; e += TTN_WG) S.Gb[(e / rm) * 128 + e % rm] = S.ldsX[(e / rm) * 128 + e % rm];
+            __syncthreads();
+        }
+        int r = 0, rk = 0;
+        if (ok) {
+            // core C = L_A^T L_B  (rm x rm)
+            wg_gemm(rm, rm, rm, tview(Gav), Gbv, Ccv, 1.0, 0.0, lds);
+            for (int e = tid; e < rm * rm; e += TTN_WG) S.ldsX[(e / rm) * 128 + e % rm] = S.Cc[(e / rm) * 128 + e % rm];
+            __syncthreads();
+            const int nsw = wg_svd_cols(P, S, rm, S.ldsX, 128, true);
+            nsw_total += (nsw < 0 ? -nsw : nsw);
+            ok = (nsw > 0) && (S.sigs[rm - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[rm - 1] * S.sigs[rm - 1] > S.scal[0]);
+        }
+        if (ok) {
+            r = wg_rank_rule(P, S, rm, p, s0);
+            rk = r < rm ? r : rm;                                           // columns that carry data
+            // X_s[:, j] = x_j * (sqrt(s0)/sA) / sigma_j^2.5 -> T1 ;  X_t[:, j] = x_j * (sqrt(s0)/sB) / sigma_j^1.5 -> T2
+            const double fa = sqrt(s0) / sA, fb = sqrt(s0) / sB;
+            for (int e = tid; e < rm * rk; e += TTN_WG) {
+                const int row = e % rm, j = e / rm;
+                const double sj = S.sigs[j], xv = S.ldsX[S.perm[j] * 128 + row];
+                const double rs = sqrt(sj);
+                S.T1[j * 128 + row] = xv * (fa / (sj * sj * rs));
+                S.T2[j * 128 + row] = xv * (fb / (sj * rs));
+            }
+            __syncthreads();
+            const View T1v = mkview(S.T1, plain(1), plain(128));
+            const View T2v = mkview(S.T2, plain(1), plain(128));
+            double* LfT = S.M;                                              // p x rk, column-major (ld = p)
+            double* RfT = S.M + (long long)p * rk;                          // rk x q, row-major (ld = q)
+            const View Lft = mkview(LfT, plain(1), plain(p));
+            const View Rft = mkview(RfT, plain(q), plain(1));
+            // Lf = A' * (L_B * (C^T * X_s))     (ldsX is free again: use it as the second temporary)
+            wg_gemm(rm, rk, rm, tview(Ccv), T1v, mkview(S.T3, plain(1), plain(128)), 1.0, 0.0, lds);
+            wg_gemm(rm, rk, rm, Gbv, mkview(S.T3, plain(1), plain(128)), T1v, 1.0, 0.0, lds);
+            wg_gemm(p, rk, rm, Ap, T1v, Lft, 1.0, 0.0, lds);
+            // Rf = (L_A * X_t)^T * B'
+            wg_gemm(rm, rk, rm, Gav, T2v, mkview(S.T3, plain(1), plain(128)), 1.0, 0.0, lds);
+            wg_gemm(rk, q, rm, tview(mkview(S.T3, plain(1), plain(128))), Bp, Rft, 1.0, 0.0, lds);
+            // a-posteriori check: Lf^T Lf = Sigma, Rf Rf^T = Sigma
+            wg_gemm(rk, rk, p, tview(Lft), Lft, mkview(S.T1, plain(1), plain(128)), 1.0, 0.0, lds);
+            wg_gemm(rk, rk, q, Rft, tview(Rft), mkview(S.T2, plain(1), plain(128)), 1.0, 0.0, lds);
+            const double e1 = wg_check_diag(S, S.T1, 128, rk, s0);
+            const double e2 = wg_check_diag(S, S.T2, 128, rk, s0);
+            ok = (e1 <= FAST_CHECK_TOL) && (e2 <= FAST_CHECK_TOL);
+            if (ok) {
+                if (P.sv_out && step < P.sv_steps) {
+                    double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
+                    for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < rm) ? S.sigs[i] * s0 : (i < p ? 0.0 : -1.0);
+                }
+                // commit: cores are overwritten only now
+                const View Rfv = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * r});
+                const View Lo = wide ? Lfv : tview(Rfv);       // p x r
+                const View Ro = wide ? Rfv : tview(Lfv);       // r x q
+                __syncthreads();
+                for (long long e = tid; e < (long long)p * r; e += TTN_WG) {
+                    const int row = (int)(e % p), j = (int)(e / p);
+                    Lo.p[ix(Lo.r, row) + ix(Lo.c, j)] = (j < rk) ? LfT[(long long)j * p + row] : 0.0;
+                }
+                for (long long e = tid; e < (long long)r * q; e += TTN_WG) {
+                    const int j = (int)(e / q), col = (int)(e % q);
+                    Ro.p[ix(Ro.r, j) + ix(Ro.c, col)] = (j < rk) ? RfT[(long long)j * q + col] : 0.0;
+                }
+                if (tid == 0) rks[k + 1] = r;
+                __syncthreads();
+                done = true;
+                route = 0;
             }
         }
-        if ((long long)r > P.max_bond) r = (int)P.max_bond;
-        iflag[1] = r;
-    }
-    __syncthreads();
-    const int r = iflag[1];
-    if (P.sv_out && step < P.sv_steps) {
-        double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
-        for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? sigs[i] * s0 : -1.0;
+        PROF_MARK(6)
     }
 
-    PROF_MARK(4)
-    // ---- 6. outputs.  left factor (p x r): x_j * sqrt(s0)/sqrt(sig_j) ; right factor (r x q):
-    //         (x_j^T M_scaled) * sqrt(s0) / (sig_j*sqrt(sig_j)) ----
-    const View Lfv = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));     // (mr x r)
-    const View Rfv = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * r});                 // (r x mc)
-    const View Lo = wide ? Lfv : tview(Rfv);       // p x r
-    const View Ro = wide ? Rfv : tview(Lfv);       // r x q
-    // Columns the Jacobi left alone as numerically zero (norm^2 <= aneg, i.e. sigma_j <= sqrt(m)*eps*sigma_max) are
-    // NOT orthogonal to the dominant directions relative to their own size, so x_j/sigma_j is not a singular
-    // vector; they contribute <= sqrt(m)*eps*sigma_max to M and are written as exact zeros.
-    const double sq0 = sqrt(s0);
-    const double aneg = scal[0];
-    for (int e = tid; e < p * r; e += TTN_WG) {
-        const int row = e % p, j = e / p;
-        const double sj = sigs[j];
-        const double xv = X[(long long)perm[j] * ldx + row];
-        const bool keep = (sj > 0.0) && (sj * sj > aneg);
-        const double lf = keep ? xv * (sq0 / sqrt(sj)) : 0.0;
-        const double us = keep ? xv * (sq0 / (sj * sqrt(sj))) : 0.0;
-        Lo.p[ix(Lo.r, row) + ix(Lo.c, j)] = lf;
-        Us[(long long)j * p + row] = us;            // Us^T stored: (r x p) row-major
+    if (!done) {
+        // ---- merge: M = A' * B'  (p x q), scaled to max|M| = 1 ----
+        const View Mv = mkview(S.M, plain(q), plain(1));
+        wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds);
+        PROF_MARK(0)
+        double mx = 0.0;
+        for (long long e = tid; e < (long long)p * q; e += TTN_WG) mx = fmax(mx, fabs(S.M[e]));
+        mx = wg_max(mx, S.red);
+        const double s0 = (mx > 0.0) ? mx : 1.0;
+        const double inv_s0 = 1.0 / s0;
+        for (long long e = tid; e < (long long)p * q; e += TTN_WG) S.M[e] *= inv_s0;
+        __syncthreads();
+        PROF_MARK(1)
+        const bool need_lq = q > p;
+        const bool x_in_lds = p <= 128;                       // fast Jacobi: X in LDS with leading dimension 128
+        double* X = x_in_lds ? S.ldsX : S.Xg;
+        const int ldx = x_in_lds ? 128 : p;
+
+        for (int attempt = (P.fast && need_lq && x_in_lds && p >= 2) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
+            bool ok = true;
+            if (attempt == 1) {
+                // =========================== route G: L = chol(M M^T) ===========================
+                wg_gemm(p, p, q, Mv, tview(Mv), mkview(S.Ga, plain(1), plain(128)), 1.0, 0.0, lds);
+                for (int e = tid; e < p * p; e += TTN_WG) S.ldsX[(e / p) * 128 + e % p] = S.Ga[(e / p) * 128 + e % p];
+                __syncthreads();
+                ok = wg_chol_lds128(p, S.ldsX, S.red, S.iflag) == 0;
+                PROF_MARK(2)
+            } else {
+                // =========================== route H: Householder LQ ===========================
+                if (need_lq) {
+                    for (long long e = tid; e < (long long)p * q; e += TTN_WG) S.M2[e] = S.M[e];
+                    __syncthreads();
+                    wg_lq_factor(p, q, S.M2, q, S.Vb, S.Wb, lds, S.Ts, S.Ss, S.taus, S.red);
+                }
+                const double* Lsrc = need_lq ? S.M2 : S.M;               // row-major, ld = q
+                for (int e = tid; e < p * p; e += TTN_WG) {
+                    const int r_ = e % p, c = e / p;                  // X[r + ldx*c] = L[r][c]
+                    const double v = Lsrc[(long long)r_ * q + c];
+                    X[(long long)c * ldx + r_] = (need_lq && c > r_) ? 0.0 : v;
+                }
+                __syncthreads();
+                PROF_MARK(2)
+            }
+            int nsw = 0;
+            if (ok) {
+                nsw = wg_svd_cols(P, S, p, X, ldx, x_in_lds);
+                nsw_total += (nsw < 0 ? -nsw : nsw);
+                if (attempt == 1)
+                    ok = (nsw > 0) && (S.sigs[p - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[p - 1] * S.sigs[p - 1] > S.scal[0]);
+                else if (nsw < 0 && tid == 0) P.status[b] = 1;
+            }
+            PROF_MARK(3)
+            if (!ok) continue;
+            const int r = wg_rank_rule(P, S, p, p, s0);
+            if (attempt == 2 && P.sv_out && step < P.sv_steps) {
+                double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
+                for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? S.sigs[i] * s0 : -1.0;
+            }
+            PROF_MARK(4)
+            // ---- outputs.  left factor (p x r): x_j * sqrt(s0)/sqrt(sig_j) ; right factor (r x q):
+            //      (x_j^T M_scaled) * sqrt(s0) / (sig_j*sqrt(sig_j)).  Columns the Jacobi left alone as numerically
+            //      zero (norm^2 <= aneg) are not singular vectors relative to their own size: written as exact zeros.
+            const View Rfv = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * r});                 // (r x mc)
+            const View Lo = wide ? Lfv : tview(Rfv);       // p x r
+            const View Ro = wide ? Rfv : tview(Lfv);       // r x q
+            const double sq0 = sqrt(s0);
+            const double aneg = S.scal[0];
+            for (int e = tid; e < p * r; e += TTN_WG) {
+                const int row = e % p, j = e / p;
+                const double sj = S.sigs[j];
+                const double xv = X[(long long)S.perm[j] * ldx + row];
+                const bool keep = (sj > 0.0) && (sj * sj > aneg);
+                const double lf = keep ? xv * (sq0 / sqrt(sj)) : 0.0;
+                const double us = keep ? xv * (sq0 / (sj * sqrt(sj))) : 0.0;
+                Lo.p[ix(Lo.r, row) + ix(Lo.c, j)] = lf;
+                S.Us[(long long)j * p + row] = us;            // Us^T stored: (r x p) row-major
+            }
+            __syncthreads();
+            wg_gemm(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, Ro, 1.0, 0.0, lds);
+            if (attempt == 1) {
+                wg_gemm(r, r, q, Ro, tview(Ro), mkview(S.T2, plain(1), plain(128)), 1.0, 0.0, lds);
+                const double e2 = wg_check_diag(S, S.T2, 128, r, s0);
+                if (!(e2 <= FAST_CHECK_TOL)) continue;                     // redo with Householder (M is intact)
+                if (P.sv_out && step < P.sv_steps) {
+                    double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
+                    for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? S.sigs[i] * s0 : -1.0;
+                }
+            }
+            if (tid == 0) rks[k + 1] = r;
+            __syncthreads();
+            done = true;
+            route = attempt;
+            PROF_MARK(5)
+        }
+    }
+    if (tid == 0) {
+        P.sweep_stats[b] += nsw_total;
+        if (P.prof && step < 120)
+            P.prof[(long long)P.tt.batch * 8 + (long long)b * 120 + step] = ((long long)route << 48) | ((long long)p << 32) | (long long)nsw_total;
     }
     __syncthreads();
-    wg_gemm(r, q, p, mkview(Us, plain(p), plain(1)), Mv, Ro, 1.0, 0.0, lds);
-    if (tid == 0) rks[k + 1] = r;
-    __syncthreads();
-    PROF_MARK(5)
 #undef PROF_MARK
 }
 
@@ -670,4 +952,16 @@ __global__ void __launch_bounds__(TTN_WG) k_dot(DotArgs P) {
         double* tmp = Mc; Mc = Mn; Mn = tmp;
     }
     if (threadIdx.x == 0) P.out[t] = Mc[0];
+}
+
+// -------------------------------------------------------------------------------------------------
+// kernel unit-test hook for wg_gemm (tests/test_gpu_kernels.py): one workgroup, plain row-major operands
+// (optionally viewed transposed so both LDS staging maps are exercised)
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TTN_WG) k_selftest_gemm(int m, int n, int k, double* A, double* B, double* C, double alpha,
+                                                         double beta, int ta, int tb) {
+    extern __shared__ double lds[];
+    const View Av = ta ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));     // ta: A stored k x m
+    const View Bv = tb ? mkview(B, plain(1), plain(k)) : mkview(B, plain(n), plain(1));     // tb: B stored n x k
+    wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), alpha, beta, lds);
 }

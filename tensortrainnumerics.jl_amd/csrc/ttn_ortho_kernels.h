@@ -4,7 +4,7 @@
 #include "ttn_common.h"
 #include "ttn_dense_kernels.h"
 
-#define ORTHO_LDS_BYTES ((GEMM_LDS_DOUBLES + 64) * sizeof(double))
+#define ORTHO_LDS_BYTES ((GEMM_LDS_TOTAL + 64) * sizeof(double))
 
 struct OrthoArgs {
     TTDev x, y;
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(TTN_WG) k_orthogonalize(OrthoArgs P) {
     const int d = X.d;
     const long long* xr = X.rks + (long long)b * (d + 1);
     long long* yr = Y.rks + (long long)b * (d + 1);
-    double* red = lds + GEMM_LDS_DOUBLES;
+    double* red = lds + GEMM_LDS_TOTAL;
     double* scr = P.scratch + (long long)b * P.scratch_stride;
     double* Tm = scr;
     double* Qb = Tm + (long long)P.mmax * P.rmax;

@@ -105,6 +105,15 @@ def apply(A: DeviceTTO, x: DeviceTT, y: DeviceTT) -> DeviceTT:
     return y
 
 
+def compress_rank_bound(dims, rks, max_bond: int, sweeps: int = 1, k: int = 0):
+    """(need, final) rank bounds of tt_compress! / _tt_bond_truncate! — see ttn_compress_rank_bound in include/ttn.h."""
+    d = len(dims)
+    need = (C.c_int64 * (d + 1))()
+    fin = (C.c_int64 * (d + 1))()
+    _lib.check(_lib.lib().ttn_compress_rank_bound(d, _i64(dims), _i64(rks), int(min(max_bond, 2 ** 62)), int(sweeps), int(k), need, fin))
+    return [int(v) for v in need], [int(v) for v in fin]
+
+
 def tt_compress_(psi: DeviceTT, max_bond: int, truncerr: float = 0.0, sweeps: int = 1) -> DeviceTT:
     assert sweeps >= 1, "sweeps must be >= 1"
     _lib.check(_lib.lib().ttn_compress(psi.h, int(min(max_bond, 2 ** 62)), float(truncerr), int(sweeps)))

@@ -243,9 +243,17 @@ def tt_compress_(psi: TTvector, max_bond: int, truncerr: float = 0.0, sweeps: in
 def _compress_call(psi: TTvector, k: int, max_bond: int, truncerr: float, sweeps: int) -> None:
     d = psi.N
     max_bond = int(min(max_bond, 2 ** 62))
-    bufs = [_f(c).copy(order="F") for c in psi.ttv_vec]
-    rks = _i64(psi.ttv_rks)
     L = _lib.lib()
+    # a rank-deficient bond can grow up to min(n r_left, n r_right, max_bond) (the reference keeps
+    # min(length(s), max_bond) singular values): size the in/out buffers for that
+    need = (C.c_int64 * (d + 1))()
+    _lib.check(L.ttn_compress_rank_bound(d, _i64(psi.ttv_dims), _i64(psi.ttv_rks), max_bond, int(sweeps), int(k), need, None))
+    bufs = []
+    for j in range(d):
+        buf = np.zeros(psi.ttv_dims[j] * int(need[j]) * int(need[j + 1]))
+        buf[: psi.ttv_vec[j].size] = _f(psi.ttv_vec[j]).reshape(-1, order="F")
+        bufs.append(buf)
+    rks = _i64(psi.ttv_rks)
     if k > 0:
         rc = L.ttn_bond_truncate_f64(d, _i64(psi.ttv_dims), _ptrs(bufs), rks, int(k), max_bond, float(truncerr))
     else:

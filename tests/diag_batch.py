@@ -29,9 +29,9 @@ if os.environ.get("TTN_PROF"):
     import ctypes as C
     out = (C.c_int64 * 8)()
     T._lib.check(T._lib.lib().ttn_prof_get(0, out))
-    names = ["merge", "scale", "LQ", "jacobi", "sort", "split"]
-    tot = sum(out[:6])
+    names = ["merge", "scale", "LQ/chol", "jacobi", "sort", "split", "routeF"]
+    tot = sum(out[:7])
     print("phase ticks (100MHz):", {n: int(v) for n, v in zip(names, out)}, "total ms", tot / 1e5)
     st = (C.c_int64 * 120)()
     T._lib.check(T._lib.lib().ttn_prof_steps(0, st))
-    print("per step (p:sweeps):", " ".join(f"{v >> 32}:{v & 0xffffffff}" for v in st[:2 * (d - 1)]))
+    print("per step (route p:sweeps):", " ".join(f"{'FGH'[(v >> 48) & 3]}{(v >> 32) & 0xffff}:{v & 0xffffffff}" for v in st[:2 * (d - 1)]))

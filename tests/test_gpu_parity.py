@@ -289,6 +289,32 @@ def test_tt_compress_reference_behaviour(T, caplog):
     assert any("TT compress: sweep 1 (L→R)" in m for m in msgs) and any("TT compress: sweep 1 (R→L)" in m for m in msgs)
 
 
+def test_compress_rank_growth_like_reference(T):
+    """The reference keeps min(length(s), max_bond) singular values, so the rank of a rank-deficient bond GROWS
+    (zero singular values are kept): ranks [1,1,1,1] with max_bond 10 become [1,2,2,1]."""
+    x = T.rand_tt((2, 2, 2), [1, 1, 1, 1], seed=3)
+    ref = O.tt_compress_(to_oracle(x), 10)
+    assert ref.ttv_rks == [1, 2, 2, 1]
+    dense = O.ttv_to_tensor(to_oracle(x))
+    got = T.tt_compress_(x, 10)
+    assert got.ttv_rks == ref.ttv_rks
+    for k, c in enumerate(got.ttv_vec):
+        assert c.shape == (2, got.ttv_rks[k], got.ttv_rks[k + 1])
+    assert np.allclose(O.ttv_to_tensor(to_oracle(got)), dense, atol=1e-14)
+    need, fin = T.device.compress_rank_bound((2, 2, 2), [1, 1, 1, 1], 10)
+    assert need == [1, 2, 2, 1] and fin == [1, 2, 2, 1]
+    # a handle whose capacity cannot hold the grown rank is refused instead of overflowing
+    dx = T.DeviceTT.from_host(T.rand_tt((2, 2, 2), [1, 1, 1, 1], seed=3))
+    with pytest.raises(T.TTNError):
+        T.device.tt_compress_(dx, 10)
+    # a wider example: random rank-2 train inside rank-5 capacity, no truncation
+    y = T.rand_tt((2,) * 6, [1, 2, 2, 2, 2, 2, 1], seed=5)
+    refy = O.tt_compress_(to_oracle(y), 50)
+    goty = T.tt_compress_(y, 50)
+    assert goty.ttv_rks == refy.ttv_rks
+    assert tt_rel_diff(to_oracle(goty), refy) < 1e-12
+
+
 def test_compress_compressible_inputs(T):
     """Restates test/test_qtt_multidim.jl:577-614 with closed-form inputs (truncerr = 1e-12)."""
     d = 12
