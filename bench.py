@@ -127,8 +127,8 @@ def main():
     dA = T.DeviceTTO(A)
     x0 = T.rand_tt((2,) * d, r, seed=30)
     dx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=B)
-    for b in range(B):                                        # distinct synthetic trains, seeds 30 + global index
-        dx.upload(b, T.rand_tt((2,) * d, r, seed=30 + rank * B + b))
+    for b, g in enumerate(T.shard.weak_train_ids(rank, world, B)):   # distinct synthetic trains, seeds 30 + global index
+        dx.upload(b, T.rand_tt((2,) * d, r, seed=30 + g))
     ycap = [a * c for a, c in zip(A.tto_rks, x0.ttv_rks)]
     dy = T.DeviceTT((2,) * d, ycap, batch=B)
 
@@ -157,10 +157,8 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    elapsed = T.shard.max_over_ranks(elapsed, dist, device="cuda")
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         dist.barrier()
     sweeps = D.compress_status(dy)
     kms = [D.event_elapsed_ms(2 * i, 2 * i + 1) for i in range(args.steps)]
@@ -184,7 +182,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * d / (elapsed / args.steps)
+        value = T.shard.cores_per_second(world, B, d, elapsed / args.steps)
         flops = sweep_algorithmic_flops(d, ycap, None, r) * B
         achieved = flops / k_avg_s / 1e12
         res = {

@@ -105,15 +105,23 @@ function tt_compress!(ψ::TTvector{Float64, N}, max_bond::Int; truncerr::Real = 
             @info "TT compress: sweep $sw (R→L)"
         end
     end
-    bufs = [copy(c) for c in ψ.ttv_vec]
+    # a rank-deficient bond may grow to min(n r_left, n r_right, max_bond): size the in/out buffers for that
+    need = zeros(Int64, N + 1)
+    _chk(ccall((:ttn_compress_rank_bound, LIB), Cint,
+        (Int64, Ptr{Int64}, Ptr{Int64}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}),
+        N, _dims(ψ.ttv_dims), ψ.ttv_rks, min(max_bond, typemax(Int64) >> 1), sweeps, 0, need, C_NULL))
+    bufs = [zeros(Float64, ψ.ttv_dims[k] * need[k] * need[k + 1]) for k in 1:N]
+    for k in 1:N
+        copyto!(bufs[k], vec(ψ.ttv_vec[k]))
+    end
     rks = copy(ψ.ttv_rks)
-    pb = _ptrs(bufs)
+    pb = Ptr{Float64}[pointer(c) for c in bufs]
     GC.@preserve bufs pb _chk(ccall((:ttn_compress_f64, LIB), Cint,
         (Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Int64, Float64, Int64),
         N, _dims(ψ.ttv_dims), pb, rks, min(max_bond, typemax(Int64) >> 1), Float64(truncerr), sweeps))
     for k in 1:N
         n = ψ.ttv_dims[k]
-        ψ.ttv_vec[k] = reshape(vec(bufs[k])[1:(n * rks[k] * rks[k + 1])], n, rks[k], rks[k + 1])
+        ψ.ttv_vec[k] = reshape(bufs[k][1:(n * rks[k] * rks[k + 1])], n, rks[k], rks[k + 1])
     end
     ψ.ttv_rks .= rks
     return ψ

@@ -1,0 +1,89 @@
+"""world_size-2 gloo test of the multi-rank path (CPU): train sharding, the max-over-ranks timing
+reduction and the gather of per-train metadata.  The arithmetic itself needs a GPU (no CPU fallback),
+so each rank runs the CPU oracle on ITS shard of tiny trains here and the test checks that the union of
+shards reproduces the single-process result exactly — the property the GPU run relies on."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, per_rank, d, r, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ttn_amd as T
+    from oracle import tt_oracle as O
+    from tests.helpers import to_oracle
+    ids = T.shard.weak_train_ids(rank, world, per_rank)
+    local = []
+    for g in ids:                                           # same seeds bench.py uses: 30 + global index
+        x = to_oracle(T.rand_tt((2,) * d, r, seed=30 + g))
+        y = O.tt_compress_(O.apply(O.Delta(d), x), r)
+        local.append((g, list(y.ttv_rks), O.norm(y)))
+    dist.barrier()
+    t = T.shard.max_over_ranks(0.25 * (rank + 1), dist)     # pretend rank 1 is the slow one
+    allres = T.shard.gather_lists(local, dist)
+    start, stop = T.shard.partition(7, rank, world)
+    q.put((rank, t, allres, (start, stop)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    import ttn_amd as T
+    from oracle import tt_oracle as O
+    from tests.helpers import to_oracle
+    world, per_rank, d, r = 2, 3, 8, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, per_rank, d, r, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    # timing reduction: MAX over ranks on every rank
+    assert all(abs(t - 0.5) < 1e-12 for _, t, _, _ in res)
+    # gathered metadata identical on both ranks, global ids 0..5 in order, equal to a single-process run
+    assert res[0][2] == res[1][2]
+    assert [g for g, _, _ in res[0][2]] == list(range(world * per_rank))
+    for g, rks, nrm in res[0][2]:
+        x = to_oracle(T.rand_tt((2,) * d, r, seed=30 + g))
+        y = O.tt_compress_(O.apply(O.Delta(d), x), r)
+        assert rks == y.ttv_rks and nrm == O.norm(y)
+    # strong partition of 7 units over 2 ranks: contiguous, disjoint, complete
+    assert res[0][3] == (0, 4) and res[1][3] == (4, 7)
+    assert T.shard.cores_per_second(2, 3, 30, 0.5) == 2 * 3 * 30 / 0.5
+
+
+def test_partition_properties():
+    import ttn_amd as T
+    for n in (0, 1, 5, 8, 30, 257):
+        for world in (1, 2, 3, 4, 8):
+            parts = [T.shard.partition(n, rk, world) for rk in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            for a, b in zip(parts, parts[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert T.shard.weak_train_ids(1, 4, 3) == [3, 4, 5]
+    assert T.shard.max_over_ranks(1.5) == 1.5 and T.shard.gather_lists([1, 2]) == [1, 2]
