@@ -391,31 +391,36 @@ __device__ inline double fast_rsqrt2(double w) {    // two Newton steps on v_rsq
     return y;
 }
 
-__device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* nrm2g, int* flag, double* red,
-                                             double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
+typedef double lds_f64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) lds_f64x2 lds_v2;
+
+// One sweep-loop instance for columns padded to 32*NT2 rows (NT2 = 1, 2, 4).  Lane `sub` of a 16-lane group owns the
+// row pairs {2*sub, 2*sub+1} + 32*t: every LDS access is a conflict-free 16-byte ds_read/write_b128 (the 16 lanes of
+// a group cover one 256-byte bank row).  Rows [m, 32*NT2) of every column must be zero on entry.
+template <int NT2>
+__device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* flag, double* red,
+                                  double tol_mult, double neg_mult, double* aneg_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
-    if (p < 2) { if (tid == 0) *aneg_out = 0.0; __syncthreads(); return 0; }
-    lds_f64* X = (lds_f64*)Xg;
-    lds_f64* nrm2 = (lds_f64*)nrm2g;
     const int grp = lane >> 4, sub = lane & 15;
     const int pe = p + (p & 1), half = pe >> 1;
-    const int nt = (m + 15) >> 4;                       // row chunks of 16
-    const int trot = (grp & 1);                          // groups 1,3 start one chunk later (bank spreading)
     const double tol = tol_mult * sqrt((double)m) * DBL_EPSILON;
     const double tol2 = tol * tol;
+    const int kk = wave * 4 + grp;                      // pair slot of this 16-lane group
+    const int roff = 2 * sub;                           // row offset of this lane inside a 32-row chunk
     double aneg = 0.0;
     int sweep = 0;
     for (; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
         // ---- refresh the cached squared norms ----
         double amax = 0.0;
-        for (int c = wave * 4 + grp; c < p; c += nwaves * 4) {
-            double a = 0.0;
-            for (int t = 0; t < nt; ++t) {
-                const int r = sub + 16 * t;
-                const double v = (r < m) ? X[c * 128 + r] : 0.0;
-                a = fma(v, v, a);
+        for (int c = kk; c < p; c += nwaves * 4) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const lds_f64x2 v = *(lds_v2*)(X + c * 128 + 32 * t + roff);
+                a0 = fma(v.x, v.x, a0);
+                a1 = fma(v.y, v.y, a1);
             }
-            a = row16_sum(a);
+            const double a = row16_sum(a0 + a1);
             if (sub == 0) nrm2[c] = a;
             amax = fmax(amax, a);
         }
@@ -428,7 +433,6 @@ __device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* n
         __syncthreads();
         int rotated = 0;
         for (int round = 0; round < pe - 1; ++round) {
-            const int kk = wave * 4 + grp;               // pair slot of this 16-lane group
             int i = 0, j = 0;
             bool act = kk < half;
             if (act) {
@@ -441,37 +445,36 @@ __device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* n
                 act = j < p;
             }
             if (act) {
-                lds_f64* xi = X + i * 128;
-                lds_f64* xj = X + j * 128;
-                double u[8], v[8];
-                double g = 0.0;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    int tt = t + trot; if (tt >= 8) tt -= 8;
-                    const int r = sub + 16 * tt;
-                    const bool in = (tt < nt) && (r < m);
-                    u[t] = in ? xi[r] : 0.0;
-                    v[t] = in ? xj[r] : 0.0;
-                    g = fma(u[t], v[t], g);
-                }
-                g = row16_sum(g);
+                lds_f64* xi = X + i * 128 + roff;
+                lds_f64* xj = X + j * 128 + roff;
                 const double a = nrm2[i], b = nrm2[j];
-                const bool rot = (a > aneg) && (b > aneg) && (g * g > tol2 * a * b);
-                if (rot) {
-                    const double zeta = (b - a) * fast_rcp(2.0 * g);
-                    const double w = fma(zeta, zeta, 1.0);
-                    const double sq = w * fast_rsqrt2(w);                  // sqrt(1 + zeta^2)
-                    const double t_ = copysign(fast_rcp(fabs(zeta) + sq), zeta);
+                lds_f64x2 u[NT2], v[NT2];
+                double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) {
+                    u[t] = *(lds_v2*)(xi + 32 * t);
+                    v[t] = *(lds_v2*)(xj + 32 * t);
+                    g0 = fma(u[t].x, v[t].x, g0);
+                    g1 = fma(u[t].y, v[t].y, g1);
+                }
+                const double g = row16_sum(g0 + g1);
+                if ((a > aneg) && (b > aneg) && (g * g > tol2 * a * b)) {
+                    // t only sets the speed of convergence (hardware rcp/sqrt accuracy is plenty);
+                    // cs = rsqrt(1+t^2) gets two Newton steps so that cs^2 + sn^2 = 1 to rounding.
+                    const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
+                    const double sq = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
+                    const double t_ = copysign(__builtin_amdgcn_rcp(fabs(zeta) + sq), zeta);
                     const double cs = fast_rsqrt2(fma(t_, t_, 1.0));
                     const double sn = cs * t_;
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        int tt = t + trot; if (tt >= 8) tt -= 8;
-                        const int r = sub + 16 * tt;
-                        if ((tt < nt) && (r < m)) {
-                            xi[r] = fma(cs, u[t], -sn * v[t]);
-                            xj[r] = fma(sn, u[t], cs * v[t]);
-                        }
+                    for (int t = 0; t < NT2; ++t) {
+                        lds_f64x2 nu, nv;
+                        nu.x = fma(cs, u[t].x, -sn * v[t].x);
+                        nu.y = fma(cs, u[t].y, -sn * v[t].y);
+                        nv.x = fma(sn, u[t].x, cs * v[t].x);
+                        nv.y = fma(sn, u[t].y, cs * v[t].y);
+                        *(lds_v2*)(xi + 32 * t) = nu;
+                        *(lds_v2*)(xj + 32 * t) = nv;
                     }
                     if (sub == 0) { nrm2[i] = fmax(a - t_ * g, 0.0); nrm2[j] = b + t_ * g; }
                     rotated = 1;
@@ -488,12 +491,24 @@ __device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* n
     return -sweep;
 }
 
+// Fast path of the one-sided Jacobi: p <= 128 columns of length m <= 128 in LDS, leading dimension 128; rows
+// [m, roundup32(m)) of every column must be ZERO (the caller pads).  See jacobi_lds128_body.
+__device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* nrm2g, int* flag, double* red,
+                                             double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
+    if (p < 2) { if (threadIdx.x == 0) *aneg_out = 0.0; __syncthreads(); return 0; }
+    lds_f64* X = (lds_f64*)Xg;
+    lds_f64* nrm2 = (lds_f64*)nrm2g;
+    if (m <= 32) return jacobi_lds128_body<1>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
+    if (m <= 64) return jacobi_lds128_body<2>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
+    return jacobi_lds128_body<4>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
+}
+
 // -------------------------------------------------------------------------------------------------
 // Cholesky G = L L^T in LDS (column-major, leading dimension 128, n <= 128), in place: on exit the lower
 // triangle holds L and the strict upper triangle is zeroed.  Returns 0, or 1 if a pivot is not safely
 // positive (d_j <= n*eps*max_diag): the caller then falls back to the Householder path.
 // -------------------------------------------------------------------------------------------------
-__device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* flag) {
+__device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
     const int tid = threadIdx.x;
     lds_f64* G = (lds_f64*)Gg;
     double dmax = 0.0;
@@ -502,9 +517,11 @@ __device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* 
     const double dmin = (double)n * DBL_EPSILON * dmax;
     if (tid == 0) *flag = 0;
     __syncthreads();
+    double pmin = dmax;
     for (int j = 0; j < n; ++j) {
         const double d = G[j * 128 + j];
         if (!(d > dmin)) { if (tid == 0) *flag = 1; break; }       // uniform: every thread reads the same d
+        pmin = fmin(pmin, d);
         const double inv = 1.0 / sqrt(d);
         __syncthreads();
         for (int i = j + tid; i < n; i += TTN_WG) G[j * 128 + i] *= inv;        // column j (incl. diagonal -> sqrt(d))
@@ -519,6 +536,8 @@ __device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* 
     }
     __syncthreads();
     const int bad = *flag;
+    // pivots lie between the extreme eigenvalues of G, so dmax/pmin is a LOWER bound of cond(G) = cond(M)^2
+    if (tid == 0) *pivmin_out = (pmin > 0.0) ? dmax / pmin : 1.0e300;
     for (int e = tid; e < n * n; e += TTN_WG) { const int c = e / n, i = e % n; if (i < c) G[c * 128 + i] = 0.0; }
     __syncthreads();
     return bad;
@@ -705,14 +724,14 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             // L_A
             for (int e = tid; e < rm * rm; e += TTN_WG) S.ldsX[(e / rm) * 128 + e % rm] = S.Ga[(e / rm) * 128 + e % rm];
             __syncthreads();
-            ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag) == 0;
+            ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
             for (int e = tid; e < rm * rm; e += TTN_WG) S.Ga[(e / rm) * 128 + e % rm] = S.ldsX[(e / rm) * 128 + e % rm];
             __syncthreads();
         }
         if (ok) {
             for (int e = tid; e < rm * rm; e += TTN_WG) S.ldsX[(e / rm) * 128 + e % rm] = S.Gb[(e / rm) * 128 + e % rm];
             __syncthreads();
-            ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag) == 0;
+            ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
             for (int e = tid; e < rm * rm; e += TTN_WG) S.Gb[(e / rm) * 128 + e % rm] = S.ldsX[(e / rm) * 128 + e % rm];
             __syncthreads();
         }
@@ -720,7 +739,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
         if (ok) {
             // core C = L_A^T L_B  (rm x rm)
             wg_gemm(rm, rm, rm, tview(Gav), Gbv, Ccv, 1.0, 0.0, lds);
-            for (int e = tid; e < rm * rm; e += TTN_WG) S.ldsX[(e / rm) * 128 + e % rm] = S.Cc[(e / rm) * 128 + e % rm];
+            for (int e = tid; e < rm * 128; e += TTN_WG) { const int c = e >> 7, r_ = e & 127; S.ldsX[e] = (r_ < rm) ? S.Cc[c * 128 + r_] : 0.0; }
             __syncthreads();
             const int nsw = wg_svd_cols(P, S, rm, S.ldsX, 128, true);
             nsw_total += (nsw < 0 ? -nsw : nsw);
@@ -810,7 +829,11 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
                 wg_gemm(p, p, q, Mv, tview(Mv), mkview(S.Ga, plain(1), plain(128)), 1.0, 0.0, lds);
                 for (int e = tid; e < p * p; e += TTN_WG) S.ldsX[(e / p) * 128 + e % p] = S.Ga[(e / p) * 128 + e % p];
                 __syncthreads();
-                ok = wg_chol_lds128(p, S.ldsX, S.red, S.iflag) == 0;
+                ok = wg_chol_lds128(p, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
+                // with truncerr > 0 the rank rule reads the SMALL singular values too: need cond(M) <= kappa_max overall
+                if (ok && P.truncerr > 0.0 && S.scal[1] > FAST_KAPPA_MAX * FAST_KAPPA_MAX) ok = false;
+                for (int e = tid; e < p * 128; e += TTN_WG) if ((e & 127) >= p) S.ldsX[e] = 0.0;      // zero row padding for the Jacobi
+                __syncthreads();
                 PROF_MARK(2)
             } else {
                 // =========================== route H: Householder LQ ===========================
@@ -820,9 +843,9 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
                     wg_lq_factor(p, q, S.M2, q, S.Vb, S.Wb, lds, S.Ts, S.Ss, S.taus, S.red);
                 }
                 const double* Lsrc = need_lq ? S.M2 : S.M;               // row-major, ld = q
-                for (int e = tid; e < p * p; e += TTN_WG) {
-                    const int r_ = e % p, c = e / p;                  // X[r + ldx*c] = L[r][c]
-                    const double v = Lsrc[(long long)r_ * q + c];
+                for (int e = tid; e < p * ldx; e += TTN_WG) {
+                    const int r_ = e % ldx, c = e / ldx;              // X[r + ldx*c] = L[r][c]; rows >= p are zero padding
+                    const double v = (r_ < p) ? Lsrc[(long long)r_ * q + c] : 0.0;
                     X[(long long)c * ldx + r_] = (need_lq && c > r_) ? 0.0 : v;
                 }
                 __syncthreads();
@@ -832,13 +855,18 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             if (ok) {
                 nsw = wg_svd_cols(P, S, p, X, ldx, x_in_lds);
                 nsw_total += (nsw < 0 ? -nsw : nsw);
-                if (attempt == 1)
-                    ok = (nsw > 0) && (S.sigs[p - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[p - 1] * S.sigs[p - 1] > S.scal[0]);
+                if (attempt == 1) ok = nsw > 0;
                 else if (nsw < 0 && tid == 0) P.status[b] = 1;
             }
             PROF_MARK(3)
             if (!ok) continue;
             const int r = wg_rank_rule(P, S, p, p, s0);
+            if (attempt == 1) {
+                // Gram route: the KEPT block must be well conditioned (error ~ eps*kappa^2, verified below); the discarded
+                // singular values only matter to the rank rule, i.e. when truncerr > 0 (then all of them must qualify).
+                const int rl = (P.truncerr > 0.0) ? p : r;
+                if (!((S.sigs[rl - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[rl - 1] * S.sigs[rl - 1] > S.scal[0]))) continue;
+            }
             if (attempt == 2 && P.sv_out && step < P.sv_steps) {
                 double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
                 for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? S.sigs[i] * s0 : -1.0;
