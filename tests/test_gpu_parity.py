@@ -430,3 +430,89 @@ def test_headline_config_properties(T):
     again = dy.download()
     assert again.ttv_rks == got.ttv_rks
     assert tt_rel_diff(to_oracle(again), to_oracle(got)) <= 1e-10
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases: general physical dimensions, short sides > 128 (global-memory Jacobi fallback), truncerr > 0 on
+# incompressible input, several sweeps, single bonds, ragged batches
+# ------------------------------------------------------------------------------------------------
+def _check_compress(T, x_prod, max_bond, truncerr=0.0, sweeps=1, tol=1e-9):
+    ref = O.tt_compress_(to_oracle(x_prod), max_bond, truncerr=truncerr, sweeps=sweeps)
+    got = T.tt_compress_(x_prod.copy(), max_bond, truncerr=truncerr, sweeps=sweeps)
+    assert got.ttv_rks == ref.ttv_rks
+    assert tt_rel_diff(to_oracle(got), ref) <= tol
+    return got
+
+
+def test_compress_general_dims_and_odd_sizes(T):
+    rng = np.random.default_rng(31)
+    x = to_product(O.rand_tt((3, 2, 5, 2, 3, 4), [1, 3, 5, 7, 6, 3, 1], rng))
+    _check_compress(T, x, 4)
+    _check_compress(T, x, 100)                      # nothing to truncate, ranks may be capped by min(rows, cols)
+    y = to_product(O.rand_tt((2, 2), [1, 2, 1], rng))
+    _check_compress(T, y, 1)
+    z = to_product(O.rand_tt((4,), [1, 1], rng))    # d = 1: no bond at all
+    got = T.tt_compress_(z.copy(), 3)
+    assert got.ttv_rks == [1, 1] and np.array_equal(got.ttv_vec[0], z.ttv_vec[0])
+
+
+def test_compress_short_side_above_128_uses_fallback(T):
+    """x ranks 70 -> y ranks 210, max_bond 100: merged matrices have a short side of 200 > 128, so the LDS-resident
+    Jacobi does not apply and the global-memory Jacobi + Householder route must give the oracle's answer."""
+    d = 16
+    x = T.Delta(d) * T.rand_tt((2,) * d, 70, seed=77)
+    assert max(x.ttv_rks) == 210
+    got = _check_compress(T, x, 100)
+    assert max(got.ttv_rks) == 100
+
+
+def test_compress_truncerr_on_incompressible_input(T):
+    d = 10
+    x = T.Delta(d) * T.rand_tt((2,) * d, 8, seed=5)
+    for te in (1e-1, 1e-2, 1e-6):
+        _check_compress(T, x, 1000, truncerr=te)
+    _check_compress(T, x, 6, truncerr=1e-3, sweeps=2)
+
+
+def test_bond_truncate_every_bond(T):
+    d = 7
+    x = T.Delta(d) * T.rand_tt((2,) * d, 4, seed=9)
+    for k in range(1, d):
+        ref = to_oracle(x)
+        O.tt_bond_truncate_(ref, k, max_bond=5)
+        got = x.copy()
+        y = T._tt_bond_truncate_(got, k, max_bond=5)
+        assert got.ttv_rks == ref.ttv_rks
+        assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
+        assert y.ttv_ot[k - 1] == 0 and tt_rel_diff(to_oracle(y), ref) <= 1e-9      # the returned orthogonalize(psi; i=k)
+
+
+def test_ragged_batch_different_ranks_per_train(T):
+    d = 8
+    A = T.Delta(d)
+    rks = [[1, 2, 3, 3, 3, 3, 3, 2, 1], [1, 2, 4, 8, 8, 8, 4, 2, 1], [1, 1, 1, 1, 1, 1, 1, 1, 1]]
+    xs = [T.rand_tt((2,) * d, r, seed=40 + i) for i, r in enumerate(rks)]
+    cap = [max(r[m] for r in rks) for m in range(d + 1)]
+    dx = T.DeviceTT((2,) * d, cap, batch=3)
+    for b, x in enumerate(xs):
+        dx.upload(b, x)
+    need, _ = T.device.compress_rank_bound((2,) * d, [a * c for a, c in zip(A.tto_rks, cap)], 6)
+    dy = T.DeviceTT((2,) * d, need, batch=3)
+    T.device.apply_compress(T.DeviceTTO(A), dx, dy, 6, 0.0, 1)
+    T.device.compress_status(dy)
+    for b, x in enumerate(xs):
+        ref = O.tt_compress_(O.apply(O.Delta(d), to_oracle(x)), 6)
+        got = dy.download(b)
+        assert got.ttv_rks == ref.ttv_rks
+        assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
+
+
+def test_fast_routes_agree_with_robust_route(T, monkeypatch):
+    """Routes F/G (Gram/Cholesky) against route H (Householder) on the same input: TTN_FAST=0 forces H."""
+    d, r = 14, 24
+    x = T.Delta(d) * T.rand_tt((2,) * d, r, seed=3)
+    fast = T.tt_compress_(x.copy(), r)
+    monkeypatch.setenv("TTN_FAST", "0")
+    robust = T.tt_compress_(x.copy(), r)
+    assert fast.ttv_rks == robust.ttv_rks
+    assert tt_rel_diff(to_oracle(fast), to_oracle(robust)) <= 1e-10
