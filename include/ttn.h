@@ -138,7 +138,7 @@ int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const do
                       int ta, int tb);
 
 /* diagnostic: with TTN_PROF=1 in the environment ttn_compress records s_memtime ticks per phase
- * (merge, scale, LQ, Jacobi, sort/rank, split) for every train; out8 receives train b's 8 counters */
+ * (merge, scale, LQ, Jacobi, sort/rank, split) for every train; out8 receives train b's 16 counters */
 int ttn_prof_get(int64_t b, int64_t* out8);
 /* per bond step (first 120 steps): (p << 32) | jacobi_sweeps, p = short side of the merged matrix */
 int ttn_prof_steps(int64_t b, int64_t* out120);

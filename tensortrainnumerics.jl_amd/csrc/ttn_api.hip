@@ -146,6 +146,10 @@ int ttn_init(int device) {
                                (int)(COMPRESS_LDS_BYTES)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_orthogonalize), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(ORTHO_LDS_BYTES)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dot), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * GEMM_LDS_TOTAL)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_selftest_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * GEMM_LDS_TOTAL)));
     g_device = device;
     g_init = true;
     return TTN_OK;
@@ -604,8 +608,8 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     P.prof = nullptr;
     if (getenv("TTN_PROF")) {
         static long long* d_prof = nullptr; static int prof_cap = 0;
-        if (prof_cap < psi->batch) { if (d_prof) hipFree(d_prof); HIPCHK(hipMalloc((void**)&d_prof, sizeof(long long) * 128 * psi->batch)); prof_cap = psi->batch; }
-        HIPCHK(hipMemsetAsync(d_prof, 0, sizeof(long long) * 128 * psi->batch, g_stream));
+        if (prof_cap < psi->batch) { if (d_prof) hipFree(d_prof); HIPCHK(hipMalloc((void**)&d_prof, sizeof(long long) * 136 * psi->batch)); prof_cap = psi->batch; }
+        HIPCHK(hipMemsetAsync(d_prof, 0, sizeof(long long) * 136 * psi->batch, g_stream));
         g_prof_batch = psi->batch;
         P.prof = d_prof; g_prof = d_prof;
     }
@@ -672,10 +676,10 @@ int ttn_prof_get(int64_t b, int64_t* out8) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     NEED_INIT();
     if (!g_prof || !out8) return fail(TTN_ERR_ARG, "no profile (set TTN_PROF=1)");
-    long long tmp[8];
-    HIPCHK(hipMemcpyAsync(tmp, g_prof + 8 * b, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
+    long long tmp[16];
+    HIPCHK(hipMemcpyAsync(tmp, g_prof + 16 * b, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
-    for (int i = 0; i < 8; ++i) out8[i] = tmp[i];
+    for (int i = 0; i < 16; ++i) out8[i] = tmp[i];
     return TTN_OK;
 }
 int ttn_prof_steps(int64_t b, int64_t* out120) {
@@ -683,7 +687,7 @@ int ttn_prof_steps(int64_t b, int64_t* out120) {
     NEED_INIT();
     if (!g_prof || !out120) return fail(TTN_ERR_ARG, "no profile (set TTN_PROF=1)");
     long long tmp[120];
-    HIPCHK(hipMemcpyAsync(tmp, g_prof + 8LL * g_prof_batch + 120 * b, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(tmp, g_prof + 16LL * g_prof_batch + 120 * b, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     for (int i = 0; i < 120; ++i) out120[i] = tmp[i];
     return TTN_OK;

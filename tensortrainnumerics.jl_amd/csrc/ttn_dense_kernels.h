@@ -87,20 +87,21 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
     lds_f64* Bs = As + GEMM_BK * GEMM_LD;
     const bool a_kfast = minstride(A.c) < minstride(A.r);
     const bool b_kfast = minstride(B.r) < minstride(B.c);
-    // staging assignment: element e = tid + 1024*u, u = 0,1 of the 128x16 (A) and 16x128 (B) chunk
-    int ar[2], akk[2], bc[2], bkk[2];
+    // staging assignment: element e = tid + 1024*u, u = 0..3 of the 128 x 32 (A) and 32 x 128 (B) chunk
+    constexpr int NU = GEMM_BM * GEMM_BK / TTN_WG;      // 4
+    int ar[NU], akk[NU], bc[NU], bkk[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int e = tid + TTN_WG * u;
-        if (a_kfast) { akk[u] = e & (GEMM_BK - 1); ar[u] = e >> 4; } else { ar[u] = e & (GEMM_BM - 1); akk[u] = e >> 7; }
-        if (b_kfast) { bkk[u] = e & (GEMM_BK - 1); bc[u] = e >> 4; } else { bc[u] = e & (GEMM_BN - 1); bkk[u] = e >> 7; }
+        if (a_kfast) { akk[u] = e & (GEMM_BK - 1); ar[u] = e / GEMM_BK; } else { ar[u] = e & (GEMM_BM - 1); akk[u] = e / GEMM_BM; }
+        if (b_kfast) { bkk[u] = e & (GEMM_BK - 1); bc[u] = e / GEMM_BK; } else { bc[u] = e & (GEMM_BN - 1); bkk[u] = e / GEMM_BN; }
     }
     for (int m0 = 0; m0 < m; m0 += GEMM_BM) {
         for (int n0 = 0; n0 < n; n0 += GEMM_BN) {
-            long long aoff[2], boff[2];
-            bool aok[2], bok[2];
+            long long aoff[NU], boff[NU];
+            bool aok[NU], bok[NU];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 aok[u] = (m0 + ar[u]) < m;
                 bok[u] = (n0 + bc[u]) < n;
                 aoff[u] = aok[u] ? ix(A.r, m0 + ar[u]) : 0;
@@ -112,16 +113,17 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
-            double av[2], bv[2];
+            // one chunk (GEMM_BK k-values) of global loads is kept in flight in registers while the MFMAs of the current one run
+            double av[NU], bv[NU];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 av[u] = (aok[u] && akk[u] < k) ? A.p[aoff[u] + ix(A.c, akk[u])] : 0.0;
                 bv[u] = (bok[u] && bkk[u] < k) ? B.p[boff[u] + ix(B.r, bkk[u])] : 0.0;
             }
             for (int k0 = 0; k0 < k; k0 += GEMM_BK) {
                 __syncthreads();                       // the previous chunk has been consumed
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < NU; ++u) {
                     As[akk[u] * GEMM_LD + ar[u]] = av[u];
                     Bs[bkk[u] * GEMM_LD + bc[u]] = bv[u];
                 }
@@ -129,7 +131,7 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
                 const int k1 = k0 + GEMM_BK;
                 if (k1 < k) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < NU; ++u) {
                         const int ga = k1 + akk[u], gb = k1 + bkk[u];
                         av[u] = (aok[u] && ga < k) ? A.p[aoff[u] + ix(A.c, ga)] : 0.0;
                         bv[u] = (bok[u] && gb < k) ? B.p[boff[u] + ix(B.r, gb)] : 0.0;
@@ -432,56 +434,134 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
         if (tid == 0) *flag = 0;
         __syncthreads();
         int rotated = 0;
-        for (int round = 0; round < pe - 1; ++round) {
-            int i = 0, j = 0;
-            bool act = kk < half;
-            if (act) {
-                if (kk == 0) { i = round; j = pe - 1; }
-                else {
-                    i = round + kk; if (i >= pe - 1) i -= pe - 1;
-                    j = round + pe - 1 - kk; if (j >= pe - 1) j -= pe - 1;
-                }
-                if (i > j) { const int t_ = i; i = j; j = t_; }
-                act = j < p;
-            }
-            if (act) {
-                lds_f64* xi = X + i * 128 + roff;
-                lds_f64* xj = X + j * 128 + roff;
-                const double a = nrm2[i], b = nrm2[j];
-                lds_f64x2 u[NT2], v[NT2];
-                double g0 = 0.0, g1 = 0.0;
+        // Block ordering.  The columns form nb blocks of 4 (nbp = nb rounded up to a power of two, phantom blocks idle).
+        //  phase 0: the 6 pairs inside every block;
+        //  then log2(nbp) LEVELS of a recursive tournament: at a level the blocks are split into groups of gs, each
+        //  group into a stationary half and a moving half; in round r wave (group, a) rotates its stationary block
+        //  against moving block (a + r) mod h — 16 cross pairs in 4 inner rounds, the 4 lane groups of the wave taking
+        //  the 4 disjoint pairs of an inner round.  nbp-1 block rounds per sweep, every pair exactly once.
+        // The Jacobi is LDS-write-bandwidth bound (a rotation rewrites both columns), so the stationary column of each
+        // lane group is kept in REGISTERS for the whole level and only the moving columns go through LDS: half the LDS
+        // traffic of a plain round-robin.  Inner rounds need no workgroup barrier (one wave owns the block pair and its
+        // LDS operations execute in order); workgroup barriers: one per block round.
+        const int nb = (p + 3) >> 2;
+        int nbp = 1;
+        while (nbp < nb) nbp <<= 1;
+#define JROT_MATH                                                                                             \
+                const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);                                  \
+                const double sq = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));                                \
+                const double t_ = copysign(__builtin_amdgcn_rcp(fabs(zeta) + sq), zeta);                      \
+                const double cs = fast_rsqrt2(fma(t_, t_, 1.0));                                              \
+                const double sn = cs * t_;
+        // ---- phase 0: pairs inside the blocks 2*wave and 2*wave+1 (both columns through LDS) ----
+        {
+            const int blk = 2 * wave + (grp >> 1);
+            if (blk < nb) {
+                const int c0 = 4 * blk, h = grp & 1;
 #pragma unroll
-                for (int t = 0; t < NT2; ++t) {
-                    u[t] = *(lds_v2*)(xi + 32 * t);
-                    v[t] = *(lds_v2*)(xj + 32 * t);
-                    g0 = fma(u[t].x, v[t].x, g0);
-                    g1 = fma(u[t].y, v[t].y, g1);
-                }
-                const double g = row16_sum(g0 + g1);
-                if ((a > aneg) && (b > aneg) && (g * g > tol2 * a * b)) {
-                    // t only sets the speed of convergence (hardware rcp/sqrt accuracy is plenty);
-                    // cs = rsqrt(1+t^2) gets two Newton steps so that cs^2 + sn^2 = 1 to rounding.
-                    const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
-                    const double sq = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
-                    const double t_ = copysign(__builtin_amdgcn_rcp(fabs(zeta) + sq), zeta);
-                    const double cs = fast_rsqrt2(fma(t_, t_, 1.0));
-                    const double sn = cs * t_;
+                for (int rr = 0; rr < 3; ++rr) {
+                    // rr = 0: (0,1),(2,3)   rr = 1: (0,2),(1,3)   rr = 2: (0,3),(1,2)
+                    const int i = c0 + ((rr == 0) ? 2 * h : h);
+                    const int j = c0 + ((rr == 0) ? 2 * h + 1 : ((rr == 1) ? h + 2 : 3 - h));
+                    if (i < p && j < p) {
+                        lds_f64* xi = X + i * 128 + roff;
+                        lds_f64* xj = X + j * 128 + roff;
+                        const double a = nrm2[i], b = nrm2[j];
+                        lds_f64x2 u[NT2], v[NT2];
+                        double g0 = 0.0, g1 = 0.0;
 #pragma unroll
-                    for (int t = 0; t < NT2; ++t) {
-                        lds_f64x2 nu, nv;
-                        nu.x = fma(cs, u[t].x, -sn * v[t].x);
-                        nu.y = fma(cs, u[t].y, -sn * v[t].y);
-                        nv.x = fma(sn, u[t].x, cs * v[t].x);
-                        nv.y = fma(sn, u[t].y, cs * v[t].y);
-                        *(lds_v2*)(xi + 32 * t) = nu;
-                        *(lds_v2*)(xj + 32 * t) = nv;
+                        for (int t = 0; t < NT2; ++t) {
+                            u[t] = *(lds_v2*)(xi + 32 * t);
+                            v[t] = *(lds_v2*)(xj + 32 * t);
+                            g0 = fma(u[t].x, v[t].x, g0);
+                            g1 = fma(u[t].y, v[t].y, g1);
+                        }
+                        const double g = row16_sum(g0 + g1);
+                        if ((a > aneg) && (b > aneg) && (g * g > tol2 * a * b)) {
+                            JROT_MATH
+#pragma unroll
+                            for (int t = 0; t < NT2; ++t) {
+                                lds_f64x2 nu, nv;
+                                nu.x = fma(cs, u[t].x, -sn * v[t].x);
+                                nu.y = fma(cs, u[t].y, -sn * v[t].y);
+                                nv.x = fma(sn, u[t].x, cs * v[t].x);
+                                nv.y = fma(sn, u[t].y, cs * v[t].y);
+                                *(lds_v2*)(xi + 32 * t) = nu;
+                                *(lds_v2*)(xj + 32 * t) = nv;
+                            }
+                            if (sub == 0) { nrm2[i] = fmax(a - t_ * g, 0.0); nrm2[j] = b + t_ * g; }
+                            rotated = 1;
+                        }
                     }
-                    if (sub == 0) { nrm2[i] = fmax(a - t_ * g, 0.0); nrm2[j] = b + t_ * g; }
-                    rotated = 1;
+                    __builtin_amdgcn_wave_barrier();
                 }
+            }
+        }
+        __syncthreads();
+        // ---- levels ----
+        for (int gs = nbp; gs >= 2; gs >>= 1) {
+            const int h = gs >> 1;
+            const bool wact = wave < (nbp >> 1);
+            const int gam = wact ? wave / h : 0, aa = wact ? wave % h : 0;
+            const int ci = 4 * (gam * gs + aa) + grp;                       // stationary column of this lane group
+            const bool iact = wact && ci < p;
+            lds_f64* xi = X + ci * 128 + roff;
+            lds_f64x2 u[NT2];
+            double a = 0.0;
+            if (iact) {
+                a = nrm2[ci];
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) u[t] = *(lds_v2*)(xi + 32 * t);
+            }
+            for (int r = 0; r < h; ++r) {
+                if (iact) {
+                    int mrot = aa + r; if (mrot >= h) mrot -= h;
+                    const int cjb = 4 * (gam * gs + h + mrot);
+#pragma unroll
+                    for (int sft = 0; sft < 4; ++sft) {
+                        const int cj = cjb + ((grp + sft) & 3);
+                        if (cj < p) {
+                            lds_f64* xj = X + cj * 128 + roff;
+                            const double b = nrm2[cj];
+                            lds_f64x2 v[NT2];
+                            double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+                            for (int t = 0; t < NT2; ++t) {
+                                v[t] = *(lds_v2*)(xj + 32 * t);
+                                g0 = fma(u[t].x, v[t].x, g0);
+                                g1 = fma(u[t].y, v[t].y, g1);
+                            }
+                            const double g = row16_sum(g0 + g1);
+                            if ((a > aneg) && (b > aneg) && (g * g > tol2 * a * b)) {
+                                JROT_MATH
+#pragma unroll
+                                for (int t = 0; t < NT2; ++t) {
+                                    lds_f64x2 nu, nv;
+                                    nu.x = fma(cs, u[t].x, -sn * v[t].x);
+                                    nu.y = fma(cs, u[t].y, -sn * v[t].y);
+                                    nv.x = fma(sn, u[t].x, cs * v[t].x);
+                                    nv.y = fma(sn, u[t].y, cs * v[t].y);
+                                    u[t] = nu;
+                                    *(lds_v2*)(xj + 32 * t) = nv;
+                                }
+                                if (sub == 0) nrm2[cj] = b + t_ * g;
+                                a = fmax(a - t_ * g, 0.0);
+                                rotated = 1;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __syncthreads();                                           // the moving blocks change hands
+            }
+            if (iact) {
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) *(lds_v2*)(xi + 32 * t) = u[t];
+                if (sub == 0) nrm2[ci] = a;
             }
             __syncthreads();
         }
+#undef JROT_MATH
         if (rotated) atomicOr(flag, 1);
         __syncthreads();
         const int any = *flag;
@@ -510,6 +590,7 @@ __device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* n
 // -------------------------------------------------------------------------------------------------
 __device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
     const int tid = threadIdx.x;
+    const int ti = tid & 127, tc = tid >> 7;             // row within a column, column group (8 columns per pass)
     lds_f64* G = (lds_f64*)Gg;
     double dmax = 0.0;
     for (int j = tid; j < n; j += TTN_WG) dmax = fmax(dmax, G[j * 128 + j]);
@@ -517,28 +598,34 @@ __device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* 
     const double dmin = (double)n * DBL_EPSILON * dmax;
     if (tid == 0) *flag = 0;
     __syncthreads();
+    // Right-looking, ONE barrier per step: column j stays UNSCALED while it is used
+    // (G[i][c] -= G[i][j] * G[c][j] / d_j) and all columns are scaled by 1/sqrt(d_j) in a final pass.
     double pmin = dmax;
+    int bad = 0;
     for (int j = 0; j < n; ++j) {
-        const double d = G[j * 128 + j];
-        if (!(d > dmin)) { if (tid == 0) *flag = 1; break; }       // uniform: every thread reads the same d
+        const double d = G[j * 128 + j];                 // final value of the pivot: every thread reads the same d
+        if (!(d > dmin)) { bad = 1; break; }
         pmin = fmin(pmin, d);
-        const double inv = 1.0 / sqrt(d);
-        __syncthreads();
-        for (int i = j + tid; i < n; i += TTN_WG) G[j * 128 + i] *= inv;        // column j (incl. diagonal -> sqrt(d))
-        __syncthreads();
-        // trailing update: G[i][c] -= L[i][j]*L[c][j] for j < c <= i   (column c, rows c..n-1)
-        const int nt = n - j - 1;
-        for (int e = tid; e < nt * nt; e += TTN_WG) {
-            const int c = j + 1 + e / nt, i = j + 1 + e % nt;
-            if (i >= c) G[c * 128 + i] = fma(-G[j * 128 + i], G[j * 128 + c], G[c * 128 + i]);
+        const double dinv = 1.0 / d;
+        if (ti > j && ti < n) {
+            const double lij = G[j * 128 + ti] * dinv;   // G[i][j] / d_j
+            for (int c = j + 1 + tc; c <= ti; c += 8)
+                G[c * 128 + ti] = fma(-lij, G[j * 128 + c], G[c * 128 + ti]);
         }
         __syncthreads();
     }
-    __syncthreads();
-    const int bad = *flag;
+    if (!bad) {
+        for (int c = tc; c < n; c += 8) {
+            const double inv = 1.0 / sqrt(G[c * 128 + c]);
+            __builtin_amdgcn_wave_barrier();
+            if (ti > c && ti < n) G[c * 128 + ti] *= inv;
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += TTN_WG) G[c * 128 + c] = sqrt(G[c * 128 + c]);
+    }
     // pivots lie between the extreme eigenvalues of G, so dmax/pmin is a LOWER bound of cond(G) = cond(M)^2
-    if (tid == 0) *pivmin_out = (pmin > 0.0) ? dmax / pmin : 1.0e300;
-    for (int e = tid; e < n * n; e += TTN_WG) { const int c = e / n, i = e % n; if (i < c) G[c * 128 + i] = 0.0; }
+    if (tid == 0) *pivmin_out = (!bad && pmin > 0.0) ? dmax / pmin : 1.0e300;
+    for (int e = tid; e < n * 128; e += TTN_WG) { const int c = e >> 7, i = e & 127; if (i < c) G[c * 128 + i] = 0.0; }
     __syncthreads();
     return bad;
 }
@@ -696,7 +783,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
     S.T3 = S.T2 + 128 * 128;
 
     long long t_prev = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
-#define PROF_MARK(slot) if (P.prof) { __syncthreads(); if (tid == 0) { long long t_now = (long long)__builtin_amdgcn_s_memtime(); P.prof[(long long)b * 8 + (slot)] += t_now - t_prev; t_prev = t_now; } }
+#define PROF_MARK(slot) if (P.prof) { __syncthreads(); if (tid == 0) { long long t_now = (long long)__builtin_amdgcn_s_memtime(); P.prof[(long long)b * 16 + (slot)] += t_now - t_prev; t_prev = t_now; } }
 
     const View Lfv = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));     // (mr x r)
     int route = 2;                                        // 0 = F, 1 = G, 2 = H (for the diagnostics)
@@ -721,6 +808,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
         if (ok) {
             wg_gemm(rm, rm, p, tview(Ap), Ap, Gav, 1.0 / (sA * sA), 0.0, lds);          // A'^T A'
             wg_gemm(rm, rm, q, Bp, tview(Bp), Gbv, 1.0 / (sB * sB), 0.0, lds);          // B' B'^T
+            PROF_MARK(8)
             // L_A
             for (int e = tid; e < rm * rm; e += TTN_WG) S.ldsX[(e / rm) * 128 + e % rm] = S.Ga[(e / rm) * 128 + e % rm];
             __syncthreads();
@@ -737,6 +825,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
         }
         int r = 0, rk = 0;
         if (ok) {
+            PROF_MARK(9)
             // core C = L_A^T L_B  (rm x rm)
             wg_gemm(rm, rm, rm, tview(Gav), Gbv, Ccv, 1.0, 0.0, lds);
             for (int e = tid; e < rm * 128; e += TTN_WG) { const int c = e >> 7, r_ = e & 127; S.ldsX[e] = (r_ < rm) ? S.Cc[c * 128 + r_] : 0.0; }
@@ -744,6 +833,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             const int nsw = wg_svd_cols(P, S, rm, S.ldsX, 128, true);
             nsw_total += (nsw < 0 ? -nsw : nsw);
             ok = (nsw > 0) && (S.sigs[rm - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[rm - 1] * S.sigs[rm - 1] > S.scal[0]);
+            PROF_MARK(10)
         }
         if (ok) {
             r = wg_rank_rule(P, S, rm, p, s0);
@@ -827,6 +917,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             if (attempt == 1) {
                 // =========================== route G: L = chol(M M^T) ===========================
                 wg_gemm(p, p, q, Mv, tview(Mv), mkview(S.Ga, plain(1), plain(128)), 1.0, 0.0, lds);
+                PROF_MARK(7)
                 for (int e = tid; e < p * p; e += TTN_WG) S.ldsX[(e / p) * 128 + e % p] = S.Ga[(e / p) * 128 + e % p];
                 __syncthreads();
                 ok = wg_chol_lds128(p, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
@@ -911,7 +1002,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
     if (tid == 0) {
         P.sweep_stats[b] += nsw_total;
         if (P.prof && step < 120)
-            P.prof[(long long)P.tt.batch * 8 + (long long)b * 120 + step] = ((long long)route << 48) | ((long long)p << 32) | (long long)nsw_total;
+            P.prof[(long long)P.tt.batch * 16 + (long long)b * 120 + step] = ((long long)route << 48) | ((long long)p << 32) | (long long)nsw_total;
     }
     __syncthreads();
 #undef PROF_MARK
