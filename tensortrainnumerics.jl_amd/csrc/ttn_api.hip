@@ -462,11 +462,11 @@ int ttn_apply(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y) {
     if (x->batch != y->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
     if (x == y) return fail(TTN_ERR_ARG, "ttn_apply: output must not alias the input");
     const int d = x->d;
-    long long maxpq = 0;
+    long long maxfib = 0;
     for (int m = 0; m <= d; ++m) if (y->cap[m] < A->rks[m] * x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_apply: destination capacity too small");
-    for (int k = 0; k < d; ++k) maxpq = std::max<long long>(maxpq, (long long)A->rks[k] * x->bound[k] * A->rks[k + 1] * x->bound[k + 1]);
+    for (int k = 0; k < d; ++k) maxfib = std::max<long long>(maxfib, (long long)x->bound[k] * x->bound[k + 1]);
     hipLaunchKernelGGL(k_ranks_mul_op, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), A->dev(), x->dev());
-    hipLaunchKernelGGL(k_apply, stream_grid(maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, A->dev(), x->dev(), y->dev());
+    hipLaunchKernelGGL(k_apply, stream_grid(maxfib, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, A->dev(), x->dev(), y->dev());
     HIPCHK(hipGetLastError());
     for (int m = 0; m <= d; ++m) y->bound[m] = A->rks[m] * x->bound[m];
     std::fill(y->ot.begin(), y->ot.end(), 0);     // zeros_tt (tt_operations.jl:103)

@@ -76,10 +76,21 @@ struct GemmDesc {
 
 // The body is deliberately NOT inlined (17 call sites) and takes its operands through a descriptor in LDS: only two
 // pointers cross the call boundary.
+// workgroup-uniform values read from LDS land in VGPRs; readfirstlane moves them to SGPRs (the GEMM is VGPR-starved)
+__device__ inline int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline long long uni64(long long v) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ inline double unif64(double v) { union { double d; long long i; } u; u.d = v; u.i = uni64(u.i); return u.d; }
+__device__ inline Idx uniIdx(const Idx& d) { return Idx{uni32(d.q), uni64(d.lo), uni64(d.hi)}; }
+__device__ inline View uniView(const View& v) { return View{(double*)uni64((long long)v.p), uniIdx(v.r), uniIdx(v.c)}; }
+
 __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
-    const int m = dsc->m, n = dsc->n, k = dsc->k;
-    const View A = dsc->A, B = dsc->B, C = dsc->C;
-    const double alpha = dsc->alpha, beta = dsc->beta;
+    const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
+    const View A = uniView(dsc->A), B = uniView(dsc->B), C = uniView(dsc->C);
+    const double alpha = unif64(dsc->alpha), beta = unif64(dsc->beta);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 15, lk = lane >> 4;
