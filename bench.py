@@ -185,6 +185,13 @@ def main():
         value = T.shard.cores_per_second(world, B, d, elapsed / args.steps)
         flops = sweep_algorithmic_flops(d, ycap, None, r) * B
         achieved = flops / k_avg_s / 1e12
+        # HBM traffic of the dominant kernel comes from the committed rocprofv3 PMC passes of THIS command line
+        # (counters cannot be read from inside the process); only reported when the configuration matches.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01b_k_compress_traffic.json")
+        if os.path.exists(tpath) and (d, r, B, world) == (30, 64, 256, 1):
+            with open(tpath) as fh:
+                traffic = json.load(fh)["traffic_bytes_per_launch_upper"]
         res = {
             "metric": "TT cores/sec for QTT Laplacian apply+round, d=%d rank-%d" % (d, r),
             "value": round(value, 1), "unit": "TT cores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,7 +202,7 @@ def main():
                        "d": d, "rank": r, "batch_per_gpu": B, "parallelism": "trains sharded over %d GPU(s), no collective" % world,
                        "out_ranks": out_rks},
             "roofline": {"bound": "mfma", "kernel": "k_compress", "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_flops_per_launch": flops, "avg_launch_ms": round(k_avg_s * 1e3, 3),
                          "jacobi_sweeps_per_train": sweeps[0]},
         }
