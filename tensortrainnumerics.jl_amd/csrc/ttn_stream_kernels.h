@@ -36,9 +36,8 @@ __global__ void k_ranks_copy(TTDev y, TTDev x) {
 // ---------------------------------------------------------------------------------------------
 // apply:  Y_k[i, a' + Rl*v', a + Rr*v] = sum_j A_k[i,j,a',a] * X_k[j,v',v]
 // (src/tt_operations.jl:101-111; operator index fastest in the combined rank index, from the
-// reshape at :106).  One thread per (p,q) output column: reads n doubles of X, writes n doubles
-// of Y (16 B for n=2) with consecutive threads on consecutive p -> coalesced stores; the operator
-// core (n*n*Rl*Rr doubles, 36 for the Laplacian) is staged in LDS.  HBM-write bound.
+// reshape at :106).  The operator core (n*n*Rl*Rr doubles, 36 for the Laplacian) is staged in LDS.
+// HBM-write bound.
 // ---------------------------------------------------------------------------------------------
 #define TTN_APPLY_LDS_DOUBLES 4096
 // One thread per INPUT fibre (v', v): reads the n doubles X_k[:, v', v] once and writes all Rl*Rr output fibres
