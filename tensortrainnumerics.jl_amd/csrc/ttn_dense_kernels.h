@@ -14,7 +14,8 @@
 #define GEMM_BN 128
 #define GEMM_BK 16
 #define GEMM_LD 144                      // LDS leading dimension (doubles): 144 % 32 == 16 spreads a half-wave's two k-rows over all banks
-#define GEMM_LDS_DOUBLES (2 * GEMM_BK * GEMM_LD)
+#define GEMM_TILE_DOUBLES (2 * GEMM_BK * GEMM_LD)   // LDS used by the tiled (big) GEMM
+#define GEMM_LDS_DOUBLES (128 * 128)               // LDS region every GEMM may use (the one-shot small GEMM uses all of it)
 #define QR_NB 16                         // Householder panel width
 #define JACOBI_MAX_SWEEPS 40
 
@@ -185,6 +186,68 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
     __syncthreads();
 }
 
+// -------------------------------------------------------------------------------------------------
+// One-shot small GEMM: m, n <= 128, m*n <= 8192 (at most 2 MFMA tiles per wave) and the WHOLE K extent of both
+// operands fits the LDS region: k*(lda+ldb) <= GEMM_LDS_DOUBLES.  All global loads are issued at once (these GEMMs
+// are latency bound: a 64x64x128 product is 1 Mflop), one barrier, k/4 MFMAs per tile, store.  Small register
+// footprint on purpose (8 accumulator doubles per tile): the factored route issues ten of these per bond step.
+// -------------------------------------------------------------------------------------------------
+__device__ inline int small_ld(int x) { const int t = (x + 15) & ~15; return ((t & 31) == 16) ? t : t + 16; }   // == 16 mod 32
+
+__device__ __noinline__ void wg_gemm_small_impl(const GemmDesc* dsc, double* lds) {
+    const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
+    const View A = uniView(dsc->A), B = uniView(dsc->B), C = uniView(dsc->C);
+    const double alpha = unif64(dsc->alpha), beta = unif64(dsc->beta);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    // dsc->pad = 1: leading dimensions == 16 mod 32 (conflict-free fragment reads); 0: tight (2-way conflicts, fits more)
+    const int lda = uni32(dsc->pad) ? small_ld(m) : ((m + 15) & ~15), ldb = uni32(dsc->pad) ? small_ld(n) : ((n + 15) & ~15);
+    lds_f64* As = (lds_f64*)lds;                       // As[kk*lda + row]
+    lds_f64* Bs = As + k * lda;                        // Bs[kk*ldb + col]
+    const bool a_kfast = minstride(A.c) < minstride(A.r);
+    const bool b_kfast = minstride(B.r) < minstride(B.c);
+    // ---- stage all of A (m x k) and B (k x n), zero padding rows/cols up to the tile edge ----
+    const int mp = (m + 15) & ~15, np = (n + 15) & ~15;
+    for (int e = tid; e < mp * k; e += TTN_WG) {
+        int r, kk;
+        if (a_kfast) { kk = e % k; r = e / k; } else { r = e % mp; kk = e / mp; }
+        As[kk * lda + r] = (r < m) ? A.p[ix(A.r, r) + ix(A.c, kk)] : 0.0;
+    }
+    for (int e = tid; e < np * k; e += TTN_WG) {
+        int c, kk;
+        if (b_kfast) { kk = e % k; c = e / k; } else { c = e % np; kk = e / np; }
+        Bs[kk * ldb + c] = (c < n) ? B.p[ix(B.r, kk) + ix(B.c, c)] : 0.0;
+    }
+    __syncthreads();
+    const int tm = mp >> 4, tn = np >> 4, ntile = tm * tn;
+    const int k4 = k >> 2, krem = k & 3;
+    for (int tile = wave; tile < ntile; tile += (TTN_WG >> 6)) {
+        const int r0 = (tile % tm) << 4, c0 = (tile / tm) << 4;
+        mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < k4; ++t) {
+            const int kr = 4 * t + lk;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[kr * lda + r0 + li], Bs[kr * ldb + c0 + li], acc, 0, 0, 0);
+        }
+        if (krem) {                                     // k not a multiple of 4: pad the last step with zeros
+            const int kr = 4 * k4 + lk;
+            const double a = (lk < krem) ? As[kr * lda + r0 + li] : 0.0;
+            const double b = (lk < krem) ? Bs[kr * ldb + c0 + li] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int gi = r0 + lk + 4 * reg, gj = c0 + li;
+            if (gi < m && gj < n) {
+                double* cp = C.p + ix(C.r, gi) + ix(C.c, gj);
+                double v = alpha * acc[reg];
+                if (beta != 0.0) v += beta * (*cp);
+                *cp = v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, double alpha, double beta, double* lds) {
     GemmDesc* dsc = reinterpret_cast<GemmDesc*>(lds + GEMM_LDS_DOUBLES);
     __syncthreads();                         // nobody still reads what the tiles / descriptor alias
@@ -194,7 +257,16 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
         dsc->alpha = alpha; dsc->beta = beta;
     }
     __syncthreads();
-    wg_gemm_impl(dsc, lds);
+    const bool shape_ok = (m <= 128) && (n <= 128) && (((m + 15) >> 4) * ((n + 15) >> 4) <= 32);
+    const bool fits_pad = (long long)k * (small_ld(m) + small_ld(n)) <= GEMM_LDS_DOUBLES;
+    const bool fits_tight = (long long)k * (((m + 15) & ~15) + ((n + 15) & ~15)) <= GEMM_LDS_DOUBLES;
+    if (shape_ok && (fits_pad || fits_tight)) {
+        if (threadIdx.x == 0) dsc->pad = fits_pad ? 1 : 0;
+        __syncthreads();
+        wg_gemm_small_impl(dsc, lds);
+    } else {
+        wg_gemm_impl(dsc, lds);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -664,7 +736,7 @@ struct CompressArgs {
 };
 
 #define COMPRESS_LDS_X_DOUBLES (128 * 128)
-#define COMPRESS_LDS_BYTES ((COMPRESS_LDS_X_DOUBLES + 32 + 2 * QR_NB * QR_NB + QR_NB + 8 + 8 + 128) * sizeof(double))
+#define COMPRESS_LDS_BYTES ((GEMM_LDS_TOTAL + 32 + 2 * QR_NB * QR_NB + QR_NB + 8 + 8 + 128) * sizeof(double))
 #define FAST_KAPPA_MAX 128.0          // fast paths are used only when sigma_max/sigma_min <= this (error ~ eps*kappa^2)
 #define FAST_CHECK_TOL 2.0e-11        // a-posteriori bound on |Rf Rf^T - Sigma| (and Lf^T Lf - Sigma), relative
 
@@ -768,7 +840,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
 
     BondCtx S;
     S.ldsX = lds;                                         // COMPRESS_LDS_X_DOUBLES (aliases the GEMM tiles)
-    S.red = lds + COMPRESS_LDS_X_DOUBLES;                 // 32
+    S.red = lds + GEMM_LDS_TOTAL;                         // 32 (the GEMM descriptor sits right behind the X region)
     S.Ts = S.red + 32;                                    // QR_NB*QR_NB
     S.Ss = S.Ts + QR_NB * QR_NB;                          // QR_NB*QR_NB
     S.taus = S.Ss + QR_NB * QR_NB;                        // QR_NB
