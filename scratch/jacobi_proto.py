@@ -101,3 +101,27 @@ for dr in (False, True):
     print('  core cols derijk', dr, 'sweeps', n)
     n, Z = jacobi((Cc/np.abs(Cc).max()).T, derijk=dr)
     print('  core rows derijk', dr, 'sweeps', n)
+
+print("---- ill-conditioned square case (R->L ramp: step 34, kappa ~1e8) ----")
+import scipy.linalg as sla
+def capture_rl(kwant, d=30, r=64, seed=30):
+    x = to_oracle(T.rand_tt((2,)*d, r, seed=seed))
+    psi = O.apply(O.Delta(d), x)
+    for k in range(1, psi.N): O.tt_bond_truncate_(psi, k, max_bond=r)
+    for k in range(psi.N-1, 0, -1):
+        Ck, Ck1 = psi.ttv_vec[k-1], psi.ttv_vec[k]
+        d1, Dl, _ = Ck.shape; d2, _, Dr = Ck1.shape
+        M = np.einsum("sag,tgb->sabt", Ck, Ck1).reshape(d1*Dl, Dr*d2)
+        if k == kwant: return M
+        O.tt_bond_truncate_(psi, k, max_bond=r)
+for kw in (6, 5):
+    M = capture_rl(kw); M = M/np.abs(M).max()
+    s = np.linalg.svd(M, compute_uv=False); print("k", kw, M.shape, "kappa %.2e" % (s[0]/s[-1]))
+    n0,_ = jacobi(M); n1,_ = jacobi(M.T)
+    Q,R = sla.qr(M.T, mode='economic'); L = R.T
+    n2,_ = jacobi(L); n3,_ = jacobi(L.T)
+    Qp,Rp,P = sla.qr(M.T, mode='economic', pivoting=True); Lp = Rp.T
+    n4,_ = jacobi(Lp); n5,_ = jacobi(Lp.T)
+    Q2,R2 = sla.qr(Lp, mode='economic')   # second QR: Lp = Q2 R2 ; Jacobi on R2^T columns
+    n6,_ = jacobi(R2.T); n7,_ = jacobi(R2)
+    print("  sweeps: M cols %d, M rows %d, L cols %d, L rows %d, Lpiv cols %d, Lpiv rows %d, R2^T cols %d, R2 cols %d" % (n0,n1,n2,n3,n4,n5,n6,n7))

@@ -258,12 +258,28 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
     }
     __syncthreads();
     const bool shape_ok = (m <= 128) && (n <= 128) && (((m + 15) >> 4) * ((n + 15) >> 4) <= 32);
-    const bool fits_pad = (long long)k * (small_ld(m) + small_ld(n)) <= GEMM_LDS_DOUBLES;
-    const bool fits_tight = (long long)k * (((m + 15) & ~15) + ((n + 15) & ~15)) <= GEMM_LDS_DOUBLES;
-    if (shape_ok && (fits_pad || fits_tight)) {
-        if (threadIdx.x == 0) dsc->pad = fits_pad ? 1 : 0;
+    const int wpad = small_ld(m) + small_ld(n), wtight = ((m + 15) & ~15) + ((n + 15) & ~15);
+    if (shape_ok && (long long)k * wpad <= GEMM_LDS_DOUBLES) {
+        if (threadIdx.x == 0) dsc->pad = 1;
         __syncthreads();
         wg_gemm_small_impl(dsc, lds);
+    } else if (shape_ok && (long long)k * wtight <= GEMM_LDS_DOUBLES) {
+        wg_gemm_small_impl(dsc, lds);                    // pad = 0: tight leading dimensions
+    } else if (shape_ok && k <= 8 * (GEMM_LDS_DOUBLES / wtight)) {
+        // few output tiles but a long K: the tiled GEMM would keep most waves idle; run the one-shot kernel over
+        // K chunks, accumulating into C (plain-stride k index assumed only through the Views: chunks shift A.c / B.r)
+        const int kc = (GEMM_LDS_DOUBLES / wtight) & ~3;
+        for (int k0 = 0; k0 < k; k0 += kc) {
+            if (k0 > 0) __syncthreads();
+            if (threadIdx.x == 0) {
+                dsc->k = (k - k0 < kc) ? k - k0 : kc;
+                dsc->A.p = A.p + ix(A.c, k0);
+                dsc->B.p = B.p + ix(B.r, k0);
+                dsc->beta = (k0 == 0) ? beta : 1.0;
+            }
+            __syncthreads();
+            wg_gemm_small_impl(dsc, lds);
+        }
     } else {
         wg_gemm_impl(dsc, lds);
     }
