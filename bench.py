@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--rank", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
+                                                        "the multi-process path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,17 +112,23 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     dist = None
+    red_device = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     import ttn_amd as T
     from ttn_amd import device as D
-    T.ensure_init(local_rank)
+    T.ensure_init(dev_index)
 
     d, r, B = args.d, args.rank, args.batch
     A = T.Delta(d)
@@ -157,7 +165,7 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    elapsed = T.shard.max_over_ranks(elapsed, dist, device="cuda")
+    elapsed = T.shard.max_over_ranks(elapsed, dist, device=red_device)
     if dist is not None:
         dist.barrier()
     sweeps = D.compress_status(dy)

@@ -1024,7 +1024,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
                 if (ok && P.truncerr > 0.0 && S.scal[1] > FAST_KAPPA_MAX * FAST_KAPPA_MAX) ok = false;
                 for (int e = tid; e < p * 128; e += TTN_WG) if ((e & 127) >= p) S.ldsX[e] = 0.0;      // zero row padding for the Jacobi
                 __syncthreads();
-                PROF_MARK(2)
+                PROF_MARK(11)
             } else {
                 // =========================== route H: Householder LQ ===========================
                 if (need_lq) {

@@ -29,8 +29,8 @@ if os.environ.get("TTN_PROF"):
     import ctypes as C
     out = (C.c_int64 * 16)()
     T._lib.check(T._lib.lib().ttn_prof_get(0, out))
-    names = ["merge", "scale", "LQ/chol", "jacobi", "sort", "split", "F:rest", "gramG", "F:grams", "F:chols", "F:jacobi"]
-    tot = sum(out[:11])
+    names = ["merge", "scale", "LQ/chol", "jacobi", "sort", "split", "F:rest", "gramG", "F:grams", "F:chols", "F:jacobi", "G:chol"]
+    tot = sum(out[:12])
     print("phase ticks (100MHz):", {n: int(v) for n, v in zip(names, out)}, "total ms", tot / 1e5)
     st = (C.c_int64 * 120)()
     T._lib.check(T._lib.lib().ttn_prof_steps(0, st))
