@@ -744,7 +744,7 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     for (int m = 0; m <= d; ++m) rmax = std::max<long long>(rmax, x->bound[m]);
     for (int k = 0; k < d; ++k) nmax = std::max<long long>(nmax, x->dims[k]);
     const long long mm = nmax * rmax;           // rows of the tall matrices
-    const long long per_train = 2 * mm * rmax + 4 * rmax * rmax + rmax + 64;   // Tm, Qb, 4 R buffers, taus
+    const long long per_train = 2 * mm * rmax + 4 * rmax * rmax + 2 * QR_NB * mm + ((rmax + QR_NB - 1) / QR_NB) * QR_NB * QR_NB + 64;   // Tm, Qb, 4 R, Vb, Wb, T panels
     int rc = ensure_scratch(sizeof(double) * (size_t)per_train * x->batch);
     if (rc) return rc;
     rc = ensure_batch_bufs(x->batch);

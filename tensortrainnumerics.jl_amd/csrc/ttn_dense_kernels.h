@@ -285,73 +285,128 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
     }
 }
 
+template <int CTRL>
+__device__ inline double dpp_mov_f64(double v) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, true);
+    return r.d;
+}
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ inline double row16_sum(double v) {
+    v += dpp_mov_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);    // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);    // row_mirror
+    return v;
+}
+__device__ inline double fast_rcp(double x) {       // ~2^-50 relative after one Newton step
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+__device__ inline double fast_rsqrt2(double w) {    // two Newton steps on v_rsq_f64: full fp64 accuracy
+    double y = __builtin_amdgcn_rsq(w);
+    double h = 0.5 * w;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+
 // -------------------------------------------------------------------------------------------------
-// Householder LQ, factor only, blocked (compact WY), in place on a row-major p x q matrix (q >= p).
-// On exit the lower triangle of M2[:, 0:p] holds L with M = L*Q; Q is never formed.
-// Row reflector j: H_j = I - tau_j v_j v_j^T acting from the right, v_j = (0.., 1, M2[j, j+1:]).
-// Trailing update of a panel: C <- C - ((C V^T) T) V  (three wg_gemm calls).
-// Scratch: Vb (QR_NB x q), Wb (p x QR_NB) in global; Ts (QR_NB*QR_NB) + tau (QR_NB) + red in LDS.
+// Blocked Householder LQ (compact WY, panel QR_NB) of a row-major p x q matrix M2 (any p, q), in place.
+// rr = min(p, q) row reflectors H_j = I - tau_j v_j v_j^T act from the right:  M2 * H_0 ... H_{rr-1} = [L 0].
+// On exit M2[i][c], c <= i, c < rr holds L; M2[j][j+1:] holds the scaled v_j (v_j[j] = 1 implicit).
+// If Qout != null it receives the rr x q matrix Q' = first rr rows of H_{rr-1} ... H_0 (orthonormal rows,
+// M = L Q'), row-major with leading dimension q.  A column-major mm x nn matrix is the row-major nn x mm
+// matrix of its transpose, so the same routine is the thin QR  T = Q R  with Q = Q'^T, R = L^T.
+//
+// Panel: the jb x len panel is factored in LDS (global memory if it does not fit) with ONE barrier per reflector:
+// every wave recomputes the reflector of row r (no broadcast), wave w applies it to panel row r+1+w, and row r is
+// left unscaled until the panel is done.  Trailing matrix: C <- C - ((C V^T) T) V by three GEMM calls.
+// Scratch: Vb (QR_NB x q), Wb (max(p, rr) x QR_NB), Tst (ceil(rr/QR_NB) * QR_NB^2, only with Qout) in global memory;
+// Ts, Ss (QR_NB^2 each), taus (QR_NB), red in LDS behind the GEMM region.
 // -------------------------------------------------------------------------------------------------
-__device__ __noinline__ void wg_lq_factor(int p, int q, double* M2, int ld, double* Vb, double* Wb, double* lds_gemm,
-                             double* Ts, double* Ss, double* taus, double* red) {
+__device__ inline double wave64_sum_fast(double v) {
+    v = row16_sum(v);                                   // every lane of a 16-lane row holds the row sum
+    union { double d; int i[2]; } u;
+    u.d = v;
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        union { double d; int i[2]; } w;
+        w.i[0] = __builtin_amdgcn_readlane(u.i[0], 16 * r);
+        w.i[1] = __builtin_amdgcn_readlane(u.i[1], 16 * r);
+        t += w.d;
+    }
+    return t;
+}
+
+__device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, double* Vb, double* Wb, double* Tst, double* Qout,
+                                           double* lds_gemm, double* Ts, double* Ss, double* taus, double* red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
-    for (int j0 = 0; j0 < p; j0 += QR_NB) {
-        const int jb = min(QR_NB, p - j0);
+    const int rr = min(p, q);
+    double* betas = Ss;                                  // QR_NB (Ss is free while a panel is being factored)
+    double* scl = Ss + QR_NB;                            // QR_NB
+    for (int j0 = 0; j0 < rr; j0 += QR_NB) {
+        const int jb = min(QR_NB, rr - j0);
         const int len = q - j0;
-        // ---- panel factorisation (rows j0..j0+jb-1, columns j0..q-1) ----
-        for (int jj = 0; jj < jb; ++jj) {
-            const int j = j0 + jj;
-            double* row = M2 + (long long)j * ld;
+        const bool in_lds = (long long)jb * len <= GEMM_LDS_DOUBLES;
+        double* Pn = in_lds ? lds_gemm : (M2 + (long long)j0 * ld + j0);
+        const int ldp = in_lds ? len : ld;
+        __syncthreads();
+        if (in_lds) {
+            for (int e = tid; e < jb * len; e += TTN_WG) { const int r = e / len, c = e - r * len; Pn[e] = M2[(long long)(j0 + r) * ld + j0 + c]; }
+            __syncthreads();
+        }
+        // ---- panel factorisation ----
+        for (int r = 0; r < jb; ++r) {
+            const double* row = Pn + (long long)r * ldp;
             double s = 0.0;
-            for (int c = j + 1 + tid; c < q; c += TTN_WG) { const double v = row[c]; s = fma(v, v, s); }
-            const double xnorm2 = wg_sum(s, red);
-            const double alpha = row[j];
+            for (int c = r + 1 + lane; c < len; c += 64) { const double v = row[c]; s = fma(v, v, s); }
+            const double xnorm2 = wave64_sum_fast(s);
+            const double alpha = row[r];
             double tau = 0.0, scal = 0.0, beta = alpha;
             if (xnorm2 > 0.0) {
                 beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha);
                 tau = (beta - alpha) / beta;
                 scal = 1.0 / (alpha - beta);
             }
-            __syncthreads();           // everyone has read alpha
-            if (xnorm2 > 0.0) {
-                for (int c = j + 1 + tid; c < q; c += TTN_WG) row[c] *= scal;
-                if (tid == 0) row[j] = beta;
-            }
-            if (tid == 0) taus[jj] = tau;
-            __syncthreads();
-            if (tau != 0.0) {
-                // apply H_j to the remaining rows of the panel, one wave per row
-                for (int i = j + 1 + wave; i < j0 + jb; i += nwaves) {
-                    double* ri = M2 + (long long)i * ld;
-                    double w = 0.0;
-                    for (int c = j + 1 + lane; c < q; c += 64) w = fma(ri[c], row[c], w);
-                    w = wave_sum(w) + ri[j];
-                    const double tw = tau * w;
-                    for (int c = j + 1 + lane; c < q; c += 64) ri[c] = fma(-tw, row[c], ri[c]);
-                    if (lane == 0) ri[j] -= tw;
-                }
+            if (tid == 0) { taus[r] = tau; scl[r] = scal; betas[r] = beta; }
+            const int i = r + 1 + wave;                   // wave w applies H_r to panel row r+1+w
+            if (tau != 0.0 && i < jb) {
+                double* ri = Pn + (long long)i * ldp;
+                double w = 0.0;
+                for (int c = r + 1 + lane; c < len; c += 64) w = fma(ri[c], row[c], w);
+                w = fma(scal, wave64_sum_fast(w), ri[r]);
+                const double tws = tau * w * scal;
+                for (int c = r + 1 + lane; c < len; c += 64) ri[c] = fma(-tws, row[c], ri[c]);
+                if (lane == 0) ri[r] -= tau * w;
             }
             __syncthreads();
         }
-        const int rows_t = p - (j0 + jb);
-        if (rows_t <= 0) break;
-        // ---- explicit V panel (jb x len): unit diagonal, zeros to its left ----
+        // ---- write the panel back (L entries, beta on the diagonal, scaled v to the right) and the explicit V ----
         for (int e = tid; e < jb * len; e += TTN_WG) {
-            const int jj = e / len, c = e % len;         // c relative to j0
-            double v;
-            if (c < jj) v = 0.0; else if (c == jj) v = 1.0; else v = M2[(long long)(j0 + jj) * ld + j0 + c];
-            Vb[(long long)jj * len + c] = v;
+            const int r = e / len, c = e - r * len;
+            const double x = Pn[(long long)r * ldp + c];
+            const double out = (c < r) ? x : ((c == r) ? betas[r] : x * scl[r]);
+            Vb[(long long)r * len + c] = (c < r) ? 0.0 : ((c == r) ? 1.0 : out);
+            M2[(long long)(j0 + r) * ld + j0 + c] = out;
         }
         __syncthreads();
+        const int rows_t = p - (j0 + jb);
+        if (rows_t <= 0 && !Qout) break;
         View Vv = mkview(Vb, plain(len), plain(1));                       // jb x len
-        // S = V V^T  (jb x jb)
+        // S = V V^T, then T (upper triangular): T[j][j] = tau_j ; T[i][j] = -tau_j * sum_{l=i}^{j-1} T[i][l] S[l][j]
         wg_gemm(jb, jb, len, Vv, tview(Vv), mkview(Ss, plain(QR_NB), plain(1)), 1.0, 0.0, lds_gemm);
-        // T (upper triangular): T[j][j] = tau_j ; T[0:j, j] = -tau_j * T[0:j,0:j] * S[0:j, j]
-        if (tid == 0) {
-            for (int a = 0; a < jb * QR_NB; ++a) Ts[a] = 0.0;
-            for (int j = 0; j < jb; ++j) {
-                Ts[j * QR_NB + j] = taus[j];
-                for (int i = 0; i < j; ++i) {
+        if (tid < QR_NB) {                                // lane i builds row i of T: it only needs its own row
+            const int i = tid;
+            for (int j = 0; j < QR_NB; ++j) Ts[i * QR_NB + j] = 0.0;
+            if (i < jb) {
+                Ts[i * QR_NB + i] = taus[i];
+                for (int j = i + 1; j < jb; ++j) {
                     double acc = 0.0;
                     for (int l = i; l < j; ++l) acc = fma(Ts[i * QR_NB + l], Ss[l * QR_NB + j], acc);
                     Ts[i * QR_NB + j] = -taus[j] * acc;
@@ -359,24 +414,57 @@ __device__ __noinline__ void wg_lq_factor(int p, int q, double* M2, int ld, doub
             }
         }
         __syncthreads();
-        // W = C V^T (rows_t x jb), C = M2[j0+jb:, j0:]
-        View Cv = mkview(M2 + (long long)(j0 + jb) * ld + j0, plain(ld), plain(1));
+        if (Qout) for (int e = tid; e < QR_NB * QR_NB; e += TTN_WG) Tst[(long long)(j0 / QR_NB) * QR_NB * QR_NB + e] = Ts[e];
+        if (rows_t > 0) {
+            // W = C V^T (rows_t x jb), C = M2[j0+jb:, j0:] ; W <- W T ; C <- C - W V
+            View Cv = mkview(M2 + (long long)(j0 + jb) * ld + j0, plain(ld), plain(1));
+            View Wv = mkview(Wb, plain(QR_NB), plain(1));
+            wg_gemm(rows_t, jb, len, Cv, tview(Vv), Wv, 1.0, 0.0, lds_gemm);
+            for (int i = tid; i < rows_t; i += TTN_WG) {
+                double w[QR_NB], o[QR_NB];
+                for (int l = 0; l < jb; ++l) w[l] = Wb[(long long)i * QR_NB + l];
+                for (int c = 0; c < jb; ++c) {
+                    double acc = 0.0;
+                    for (int l = 0; l <= c; ++l) acc = fma(w[l], Ts[l * QR_NB + c], acc);
+                    o[c] = acc;
+                }
+                for (int c = 0; c < jb; ++c) Wb[(long long)i * QR_NB + c] = o[c];
+            }
+            __syncthreads();
+            wg_gemm(rows_t, len, jb, Wv, Vv, Cv, -1.0, 1.0, lds_gemm);
+        }
+    }
+    __syncthreads();
+    if (!Qout) return;
+    // ---- Q' = [I 0] H_{rr-1} ... H_0, panels in reverse: Qs <- Qs - ((Qs V^T) T^T) V on Qs = Q'[j0:, j0:] ----
+    for (long long e = tid; e < (long long)rr * q; e += TTN_WG) { const int i = (int)(e / q), c = (int)(e - (long long)i * q); Qout[e] = (i == c) ? 1.0 : 0.0; }
+    __syncthreads();
+    for (int j0 = ((rr - 1) / QR_NB) * QR_NB; j0 >= 0; j0 -= QR_NB) {
+        const int jb = min(QR_NB, rr - j0);
+        const int len = q - j0;
+        for (int e = tid; e < jb * len; e += TTN_WG) {
+            const int r = e / len, c = e - r * len;
+            Vb[e] = (c < r) ? 0.0 : ((c == r) ? 1.0 : M2[(long long)(j0 + r) * ld + j0 + c]);
+        }
+        for (int e = tid; e < QR_NB * QR_NB; e += TTN_WG) Ts[e] = Tst[(long long)(j0 / QR_NB) * QR_NB * QR_NB + e];
+        __syncthreads();
+        const int rows_q = rr - j0;
+        View Vv = mkview(Vb, plain(len), plain(1));
+        View Qs = mkview(Qout + (long long)j0 * q + j0, plain(q), plain(1));
         View Wv = mkview(Wb, plain(QR_NB), plain(1));
-        wg_gemm(rows_t, jb, len, Cv, tview(Vv), Wv, 1.0, 0.0, lds_gemm);
-        // W <- W T   (each thread one row)
-        for (int i = tid; i < rows_t; i += TTN_WG) {
+        wg_gemm(rows_q, jb, len, Qs, tview(Vv), Wv, 1.0, 0.0, lds_gemm);
+        for (int i = tid; i < rows_q; i += TTN_WG) {       // W <- W T^T : o[c] = sum_{l >= c} w[l] T[c][l]
             double w[QR_NB], o[QR_NB];
             for (int l = 0; l < jb; ++l) w[l] = Wb[(long long)i * QR_NB + l];
             for (int c = 0; c < jb; ++c) {
                 double acc = 0.0;
-                for (int l = 0; l <= c; ++l) acc = fma(w[l], Ts[l * QR_NB + c], acc);
+                for (int l = c; l < jb; ++l) acc = fma(w[l], Ts[c * QR_NB + l], acc);
                 o[c] = acc;
             }
             for (int c = 0; c < jb; ++c) Wb[(long long)i * QR_NB + c] = o[c];
         }
         __syncthreads();
-        // C <- C - W V
-        wg_gemm(rows_t, len, jb, Wv, Vv, Cv, -1.0, 1.0, lds_gemm);
+        wg_gemm(rows_q, len, jb, Wv, Vv, Qs, -1.0, 1.0, lds_gemm);
     }
     __syncthreads();
 }
@@ -463,35 +551,6 @@ __device__ __noinline__ int wg_jacobi_cols(int m, int p, double* X, int ldx, int
 //     (it sets the speed of convergence), c = rsqrt(1+t^2) gets two Newton steps so that c^2+s^2 = 1
 //     to rounding (that is what makes every applied rotation orthogonal, i.e. backward stable).
 // -------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ inline double dpp_mov_f64(double v) {
-    union { double d; int i[2]; } a, r;
-    a.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, true);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, true);
-    return r.d;
-}
-// sum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ inline double row16_sum(double v) {
-    v += dpp_mov_f64<0xB1>(v);     // quad_perm [1,0,3,2]
-    v += dpp_mov_f64<0x4E>(v);     // quad_perm [2,3,0,1]
-    v += dpp_mov_f64<0x141>(v);    // row_half_mirror
-    v += dpp_mov_f64<0x140>(v);    // row_mirror
-    return v;
-}
-__device__ inline double fast_rcp(double x) {       // ~2^-50 relative after one Newton step
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return y;
-}
-__device__ inline double fast_rsqrt2(double w) {    // two Newton steps on v_rsq_f64: full fp64 accuracy
-    double y = __builtin_amdgcn_rsq(w);
-    double h = 0.5 * w;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
-}
-
 typedef double lds_f64x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) lds_f64x2 lds_v2;
 
@@ -1030,7 +1089,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
                 if (need_lq) {
                     for (long long e = tid; e < (long long)p * q; e += TTN_WG) S.M2[e] = S.M[e];
                     __syncthreads();
-                    wg_lq_factor(p, q, S.M2, q, S.Vb, S.Wb, lds, S.Ts, S.Ss, S.taus, S.red);
+                    wg_lq_blocked(p, q, S.M2, q, S.Vb, S.Wb, nullptr, nullptr, lds, S.Ts, S.Ss, S.taus, S.red);
                 }
                 const double* Lsrc = need_lq ? S.M2 : S.M;               // row-major, ld = q
                 for (int e = tid; e < p * ldx; e += TTN_WG) {

@@ -4,7 +4,7 @@
 #include "ttn_common.h"
 #include "ttn_dense_kernels.h"
 
-#define ORTHO_LDS_BYTES ((GEMM_LDS_TOTAL + 64) * sizeof(double))
+#define ORTHO_LDS_BYTES ((GEMM_LDS_TOTAL + 32 + 2 * QR_NB * QR_NB + 2 * QR_NB) * sizeof(double))
 
 struct OrthoArgs {
     TTDev x, y;
@@ -14,71 +14,20 @@ struct OrthoArgs {
     int mmax, rmax;
 };
 
-// Thin Householder QR of the column-major mm x nn matrix Tm (ld = mm), in place.
-// Outputs: Qb (mm x rnew, ld = mm) explicit, Rb (rnew x nn, ld = rnew) with zeros below the diagonal,
-// rnew = min(mm, nn)  (the rank the reference reads from size(Matrix(F.Q), 2), src/tt_tools.jl:522).
-__device__ int wg_qr_explicit(int mm, int nn, double* Tm, double* Qb, double* Rb, double* taus, double* red) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+// Thin QR  T = Q R  of the column-major mm x nn matrix Tm (ld = mm) through the blocked Householder LQ of its
+// transpose (the same storage read as a row-major nn x mm matrix).  Outputs: Qb (mm x rnew column-major, i.e. the
+// rnew x mm row-major Q' of the LQ), Rb (rnew x nn, ld = rnew) with zeros below the diagonal; rnew = min(mm, nn)
+// (the rank the reference reads from size(Matrix(F.Q), 2), src/tt_tools.jl:522).
+struct OrthoWork { double *Vb, *Wb, *Tst, *Ts, *Ss, *taus, *red; };
+__device__ int wg_qr_explicit(int mm, int nn, double* Tm, double* Qb, double* Rb, const OrthoWork& W, double* lds) {
+    const int tid = threadIdx.x;
     const int rnew = min(mm, nn);
-    for (int j = 0; j < rnew; ++j) {
-        double* col = Tm + (long long)j * mm;
-        double s = 0.0;
-        for (int i = j + 1 + tid; i < mm; i += TTN_WG) { const double v = col[i]; s = fma(v, v, s); }
-        const double xnorm2 = wg_sum(s, red);
-        const double alpha = col[j];
-        double tau = 0.0, scal = 0.0, beta = alpha;
-        if (xnorm2 > 0.0) {
-            beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha);
-            tau = (beta - alpha) / beta;
-            scal = 1.0 / (alpha - beta);
-        }
-        __syncthreads();
-        if (xnorm2 > 0.0) {
-            for (int i = j + 1 + tid; i < mm; i += TTN_WG) col[i] *= scal;
-            if (tid == 0) col[j] = beta;
-        }
-        if (tid == 0) taus[j] = tau;
-        __syncthreads();
-        if (tau != 0.0) {
-            for (int c = j + 1 + wave; c < nn; c += nwaves) {
-                double* cc = Tm + (long long)c * mm;
-                double w = 0.0;
-                for (int i = j + 1 + lane; i < mm; i += 64) w = fma(cc[i], col[i], w);
-                w = wave_sum(w) + cc[j];
-                const double tw = tau * w;
-                for (int i = j + 1 + lane; i < mm; i += 64) cc[i] = fma(-tw, col[i], cc[i]);
-                if (lane == 0) cc[j] -= tw;
-            }
-        }
-        __syncthreads();
-    }
-    // R = triu(Tm)[0:rnew, :]
+    wg_lq_blocked(nn, mm, Tm, mm, W.Vb, W.Wb, W.Tst, Qb, lds, W.Ts, W.Ss, W.taus, W.red);
     for (int e = tid; e < rnew * nn; e += TTN_WG) {
         const int i = e % rnew, c = e / rnew;
         Rb[e] = (i <= c) ? Tm[(long long)c * mm + i] : 0.0;
     }
-    // Q = H_0 H_1 ... H_{rnew-1} * I[:, 0:rnew]  (backward accumulation)
-    for (long long e = tid; e < (long long)mm * rnew; e += TTN_WG) {
-        const int i = (int)(e % mm), c = (int)(e / mm);
-        Qb[e] = (i == c) ? 1.0 : 0.0;
-    }
     __syncthreads();
-    for (int j = rnew - 1; j >= 0; --j) {
-        const double tau = taus[j];
-        if (tau != 0.0) {
-            const double* v = Tm + (long long)j * mm;
-            for (int c = j + wave; c < rnew; c += nwaves) {
-                double* qc = Qb + (long long)c * mm;
-                double w = 0.0;
-                for (int i = j + 1 + lane; i < mm; i += 64) w = fma(qc[i], v[i], w);
-                w = wave_sum(w) + qc[j];
-                const double tw = tau * w;
-                for (int i = j + 1 + lane; i < mm; i += 64) qc[i] = fma(-tw, v[i], qc[i]);
-                if (lane == 0) qc[j] -= tw;
-            }
-        }
-        __syncthreads();
-    }
     return rnew;
 }
 
@@ -116,7 +65,16 @@ __global__ void __launch_bounds__(TTN_WG) k_orthogonalize(OrthoArgs P) {
     double* Qb = Tm + (long long)P.mmax * P.rmax;
     double* Rb0 = Qb + (long long)P.mmax * P.rmax;
     double* Rb1 = Rb0 + (long long)P.rmax * P.rmax;
-    double* taus = Rb1 + (long long)P.rmax * P.rmax;
+    double* Rc = Rb1 + (long long)P.rmax * P.rmax;                           // R factors of the right sweep ping-pong in Rc/Rd
+    double* Rd = Rc + (long long)P.rmax * P.rmax;
+    OrthoWork W;
+    W.Vb = Rd + (long long)P.rmax * P.rmax;                                  // QR_NB x mmax
+    W.Wb = W.Vb + (long long)QR_NB * P.mmax;                                 // mmax x QR_NB (>= max(nn, rnew) rows)
+    W.Tst = W.Wb + (long long)QR_NB * P.mmax;                                // ceil(rmax/QR_NB) * QR_NB^2
+    W.red = red;
+    W.Ts = red + 32;
+    W.Ss = W.Ts + QR_NB * QR_NB;
+    W.taus = W.Ss + QR_NB * QR_NB;
     if (tid == 0) dev_r_and_d_to_rks(d, X.dims, xr, 1024, yr);
     __syncthreads();
     const int ic = P.center;
@@ -137,7 +95,7 @@ __global__ void __launch_bounds__(TTN_WG) k_orthogonalize(OrthoArgs P) {
         const View Tv = mkview(Tm, plain(1), Idx{n, (long long)yl, (long long)mm});   // [al, (s + n*be)]
         wg_gemm(yl, n * rr, rl, FR, Xv, Tv, 1.0, 0.0, lds);
         double* Rn = which ? Rb0 : Rb1;
-        const int rnew = wg_qr_explicit(mm, rr, Tm, Qb, Rn, taus, red);
+        const int rnew = wg_qr_explicit(mm, rr, Tm, Qb, Rn, W, lds);
         // Y_j[s, al, be] = Q[al + yl*s, be]
         for (long long e = tid; e < (long long)mm * rnew; e += TTN_WG) {
             const int row = (int)(e % mm), be = (int)(e / mm);
@@ -150,8 +108,6 @@ __global__ void __launch_bounds__(TTN_WG) k_orthogonalize(OrthoArgs P) {
         which ^= 1;
     }
     // ---- right sweep: sites d-1..ic+1 (src/tt_tools.jl:528-536); its R factors ping-pong in Rc/Rd ----
-    double* Rc = taus + P.rmax;                                              // third R buffer (rmax x rmax)
-    double* Rd = Rc + (long long)P.rmax * P.rmax;                            // fourth
     if (tid == 0) { Rc[0] = 1.0; }
     __syncthreads();
     View FL = mkview(Rc, plain(1), plain(1));             // (rr x yr_{j+1})
@@ -167,7 +123,7 @@ __global__ void __launch_bounds__(TTN_WG) k_orthogonalize(OrthoArgs P) {
         const View Tv = mkview(Tm, plain(1), Idx{n, (long long)ynext, (long long)mm});
         wg_gemm(ynext, n * rl, rr, tview(FL), X2, Tv, 1.0, 0.0, lds);
         double* Rn = whichL ? Rc : Rd;
-        const int rnew = wg_qr_explicit(mm, rl, Tm, Qb, Rn, taus, red);
+        const int rnew = wg_qr_explicit(mm, rl, Tm, Qb, Rn, W, lds);
         // Y_j[s, al, be] = Qt[(be + ynext*s), al]   (core shape (n, rnew, ynext))
         for (long long e = tid; e < (long long)mm * rnew; e += TTN_WG) {
             const int row = (int)(e % mm), al = (int)(e / mm);
