@@ -66,6 +66,9 @@ int ttn_tt_upload(ttn_tt_t h, int64_t b, const double* const* cores, const int64
 int ttn_tt_replicate(ttn_tt_t h, int64_t src_b);
 /* current ranks / ot flags of train b (synchronises the stream) */
 int ttn_tt_ranks(ttn_tt_t h, int64_t b, int64_t* rks, int64_t* ot);
+/* bound[m] = max over the trains of the CURRENT rank of bond m (synchronises); also tightens the host-side rank
+ * bounds the capacity checks of the other calls use (they only know upper bounds after data-dependent truncations) */
+int ttn_tt_max_ranks(ttn_tt_t h, int64_t* bound);
 /* cores[k] must have room for n_k*rks[k]*rks[k+1] doubles with the CURRENT ranks (see ttn_tt_ranks) */
 int ttn_tt_download(ttn_tt_t h, int64_t b, double* const* cores);
 int ttn_tt_batch(ttn_tt_t h, int64_t* batch);
@@ -115,6 +118,9 @@ int ttn_add(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z);
 /* y = a * x            src/tt_operations.jl:256-266 (scales the first core with ot==0, else core 1;
  *                      a == 0 gives the all-zero train with ot reset to 0) */
 int ttn_scale(double a, ttn_tt_t x, ttn_tt_t y);
+/* y_b = a[b] * x_b with one factor per train (a is HOST memory, length batch): what `(1 / sqrt(dot(u, u))) * u` needs on a
+ * batch (src/solvers/euler.jl:83-85, :205-207) */
+int ttn_scale_batch(const double* a, ttn_tt_t x, ttn_tt_t y);
 /* y = orthogonalize(x; i=center)   src/tt_tools.jl:511-543 ; center is 1-based */
 int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y);
 

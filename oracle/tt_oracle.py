@@ -35,7 +35,7 @@ __all__ = [
     "qtt_polynom", "qtt_to_vector", "ttv_to_tensor", "tto_to_tensor", "qtto_to_matrix",
     "apply", "dot", "norm", "euclidean_distance", "hadamard", "add", "add_", "scale",
     "sub", "div", "orthogonalize", "svdtrunc", "svdtrunc_shadowed", "tt_bond_truncate_",
-    "tt_compress_", "copy_tt",
+    "tt_compress_", "copy_tt", "rk4_method", "euler_method",
 ]
 
 
@@ -544,3 +544,31 @@ def tt_compress_(psi: TTvector, max_bond: int, truncerr: float = 0.0, sweeps: in
         for k in range(psi.N - 1, 0, -1):
             tt_bond_truncate_(psi, k, max_bond=max_bond, truncerr=truncerr, faithful=faithful, svals_out=svals_out)
     return psi
+
+
+# --------------------------------------------------------------------------------------
+# Explicit time steppers (callers of the hot path) — src/solvers/euler.jl:76-97, :193-209
+# --------------------------------------------------------------------------------------
+def rk4_method(A: TToperator, u0: TTvector, steps, max_bond: int, normalize: bool = True) -> TTvector:
+    u = u0
+    for h in steps:
+        k1 = apply(A, u)
+        k2 = apply(A, tt_compress_(add(u, scale(h / 2, k1)), max_bond))
+        k3 = apply(A, tt_compress_(add(u, scale(h / 2, k2)), max_bond))
+        k4 = apply(A, tt_compress_(add(u, scale(h, k3)), max_bond))
+        incr = scale(h / 6, tt_compress_(add(add(add(k1, scale(2, k2)), scale(2, k3)), k4), max_bond))
+        u_new = tt_compress_(add(u, incr), max_bond)
+        if normalize:
+            u_new = scale(1 / math.sqrt(dot(u_new, u_new)), u_new)
+        u = u_new
+    return u
+
+
+def euler_method(A: TToperator, u0: TTvector, steps, normalize: bool = True) -> TTvector:
+    sol = u0
+    for h in steps:
+        update = apply(A, sol)
+        sol = orthogonalize(add(sol, scale(h, update)))
+        if normalize:
+            sol = scale(1 / math.sqrt(dot(sol, sol)), sol)
+    return sol

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ttn_tt_upload": (C.c_int, [handle, i64, pp_f64, p_i64, p_i64]),
     "ttn_tt_replicate": (C.c_int, [handle, i64]),
     "ttn_tt_ranks": (C.c_int, [handle, i64, p_i64, p_i64]),
+    "ttn_tt_max_ranks": (C.c_int, [handle, p_i64]),
     "ttn_tt_download": (C.c_int, [handle, i64, pp_f64]),
     "ttn_tt_batch": (C.c_int, [handle, p_i64]),
     "ttn_tt_copy": (C.c_int, [handle, handle]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "ttn_hadamard": (C.c_int, [handle, handle, handle]),
     "ttn_add": (C.c_int, [handle, handle, handle]),
     "ttn_scale": (C.c_int, [C.c_double, handle, handle]),
+    "ttn_scale_batch": (C.c_int, [p_f64, handle, handle]),
     "ttn_orthogonalize": (C.c_int, [handle, i64, handle]),
     "ttn_sv_capture": (C.c_int, [handle, C.c_int]),
     "ttn_sv_get": (C.c_int, [handle, i64, i64, p_f64, i64, p_i64]),

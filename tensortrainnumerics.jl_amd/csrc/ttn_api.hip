@@ -356,6 +356,23 @@ int ttn_tt_ranks(ttn_tt_t h, int64_t b, int64_t* rks, int64_t* ot) {
     return TTN_OK;
 }
 
+int ttn_tt_max_ranks(ttn_tt_t h, int64_t* bound) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!h) return fail(TTN_ERR_ARG, "null handle");
+    const int d = h->d;
+    std::vector<long long> r64((size_t)h->batch * (d + 1));
+    HIPCHK(hipMemcpyAsync(r64.data(), h->d_rks, sizeof(long long) * r64.size(), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (int m = 0; m <= d; ++m) {
+        long long mx = 1;
+        for (int b = 0; b < h->batch; ++b) mx = std::max(mx, r64[(size_t)b * (d + 1) + m]);
+        h->bound[m] = mx;
+        if (bound) bound[m] = mx;
+    }
+    return TTN_OK;
+}
+
 int ttn_tt_download(ttn_tt_t h, int64_t b, double* const* cores) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     NEED_INIT();
@@ -531,6 +548,30 @@ int ttn_scale(double a, ttn_tt_t x, ttn_tt_t y) {
     HIPCHK(hipGetLastError());
     y->bound = x->bound;
     if (a == 0.0) std::fill(y->ot.begin(), y->ot.end(), 0); else y->ot = x->ot;
+    return TTN_OK;
+}
+
+int ttn_scale_batch(const double* a, ttn_tt_t x, ttn_tt_t y) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!a || !x || !y) return fail(TTN_ERR_ARG, "null pointer");
+    if (!same_dims(x->dims, y->dims) || x->batch != y->batch) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    const int d = x->d;
+    for (int m = 0; m <= d; ++m) if (y->cap[m] < x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_scale_batch: destination capacity too small");
+    int rc = ensure_batch_bufs(x->batch);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(g_dout, a, sizeof(double) * x->batch, hipMemcpyHostToDevice, g_stream));
+    int which = 0;
+    for (int k = 0; k < d; ++k) if (x->ot[k] == 0) { which = k; break; }
+    long long maxsz = 0;
+    for (int k = 0; k < d; ++k) maxsz = std::max<long long>(maxsz, (long long)x->dims[k] * x->bound[k] * x->bound[k + 1]);
+    if (x != y) hipLaunchKernelGGL(k_ranks_copy, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), x->dev());
+    hipLaunchKernelGGL(k_scale_batch, stream_grid(maxsz, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), (const double*)g_dout, which);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g_stream));      // `a` is caller memory and g_dout is reused by ttn_dot
+    y->bound = x->bound;
+    y->ot = x->ot;
+    for (int b = 0; b < x->batch; ++b) if (a[b] == 0.0) for (int k = 0; k < d; ++k) y->ot[(size_t)b * d + k] = 0;
     return TTN_OK;
 }
 

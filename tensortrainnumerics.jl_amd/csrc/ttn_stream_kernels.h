@@ -177,6 +177,18 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_scale(TTDev x, TTDev y, doubl
         Yk[e] = zero ? 0.0 : ((k == which) ? f * Xk[e] : Xk[e]);
 }
 
+// per-train scalar: y_b = a[b] * x_b (a on the device); a[b] == 0 writes the zero train
+__global__ void __launch_bounds__(TTN_STREAM_TB) k_scale_batch(TTDev x, TTDev y, const double* a, int which) {
+    const int k = blockIdx.y, b = blockIdx.z;
+    const long long* xr = x.rks + (long long)b * (x.d + 1);
+    const long long total = (long long)x.dims[k] * xr[k] * xr[k + 1];
+    const double* Xk = x.data + (long long)b * x.stride + x.off[k];
+    double* Yk = y.data + (long long)b * y.stride + y.off[k];
+    const double f = a[b];
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+        Yk[e] = (f == 0.0) ? 0.0 : ((k == which) ? f * Xk[e] : Xk[e]);
+}
+
 // replicate train src over the whole batch (cores + ranks)
 __global__ void __launch_bounds__(TTN_STREAM_TB) k_replicate(TTDev x, int src) {
     const int b = blockIdx.y;

@@ -72,6 +72,13 @@ class DeviceTT:
         _lib.check(_lib.lib().ttn_tt_ranks(self.h, int(b), rks, ot))
         return [int(v) for v in rks], [int(v) for v in ot]
 
+    def max_ranks(self):
+        """Per-bond maximum of the current ranks over the batch (synchronises; also tightens the library's host-side
+        rank bounds)."""
+        out = (C.c_int64 * (self.N + 1))()
+        _lib.check(_lib.lib().ttn_tt_max_ranks(self.h, out))
+        return [int(v) for v in out]
+
     def download(self, b: int = 0) -> TTvector:
         rks, ot = self.ranks(b)
         cores = [np.zeros((self.dims[k], rks[k], rks[k + 1]), order="F") for k in range(self.N)]
@@ -156,6 +163,13 @@ def add(x: DeviceTT, y: DeviceTT, z: DeviceTT) -> DeviceTT:
 
 def scale(a: float, x: DeviceTT, y: DeviceTT) -> DeviceTT:
     _lib.check(_lib.lib().ttn_scale(float(a), x.h, y.h))
+    return y
+
+
+def scale_batch(a, x: DeviceTT, y: DeviceTT) -> DeviceTT:
+    """y_b = a[b] * x_b (one scalar per train)."""
+    arr = (C.c_double * x.batch)(*[float(v) for v in a])
+    _lib.check(_lib.lib().ttn_scale_batch(arr, x.h, y.h))
     return y
 
 

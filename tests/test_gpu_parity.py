@@ -516,3 +516,38 @@ def test_fast_routes_agree_with_robust_route(T, monkeypatch):
     robust = T.tt_compress_(x.copy(), r)
     assert fast.ttv_rks == robust.ttv_rks
     assert tt_rel_diff(to_oracle(fast), to_oracle(robust)) <= 1e-10
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident caller chains: rk4_method / euler_method of src/solvers/euler.jl on handles
+# ------------------------------------------------------------------------------------------------
+def test_rk4_and_euler_device_chains(T):
+    d, B = 8, 3
+    hh = 1 / d ** 2
+    A = T.toeplitz_to_qtto(-2.0, 1.0, 1.0, d)
+    A.tto_vec[0] = (-hh ** 2) * A.tto_vec[0]
+    us = [T.rand_tt((2,) * d, [1, 2, 3, 3, 3, 3, 3, 2, 1], seed=70 + b) for b in range(B)]
+    du = T.DeviceTT((2,) * d, us[0].ttv_rks, batch=B)
+    for b, u in enumerate(us):
+        du.upload(b, u)
+    dA = T.DeviceTTO(A)
+    steps = [0.05, 0.05, 0.1]
+    out = T.solvers.rk4_method(dA, du, steps, 6, normalize=True)
+    eul = T.solvers.euler_method(dA, du, steps, normalize=True)
+    for b, u in enumerate(us):
+        ref = O.rk4_method(to_oracle(A), to_oracle(u), steps, 6, normalize=True)
+        got = out.download(b)
+        assert got.ttv_rks == ref.ttv_rks
+        assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
+        assert abs(T.norm(got) - 1.0) < 1e-10
+        refe = O.euler_method(to_oracle(A), to_oracle(u), steps, normalize=True)
+        gote = eul.download(b)
+        assert gote.ttv_rks == refe.ttv_rks and gote.ttv_ot == refe.ttv_ot
+        assert tt_rel_diff(to_oracle(gote), refe) <= 1e-10
+    # dense check of the RK4 chain for one train and one step, as test/test_euler.jl:269-298 does
+    one = T.solvers.rk4_method(dA, T.DeviceTT.from_host(us[0]), [0.05], 8, normalize=False).download(0)
+    Ad, ud = O.qtto_to_matrix(to_oracle(A)), T.qtt_to_vector(us[0])
+    h = 0.05
+    K1 = Ad @ ud; K2 = Ad @ (ud + h / 2 * K1); K3 = Ad @ (ud + h / 2 * K2); K4 = Ad @ (ud + h * K3)
+    refv = ud + h / 6 * (K1 + 2 * K2 + 2 * K3 + K4)
+    assert np.linalg.norm(T.qtt_to_vector(one) - refv) / np.linalg.norm(refv) < 1e-6
