@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttn_hip.so")
+LIB_PATH = os.environ.get("TTN_LIB") or os.path.join(_HERE, "libttn_hip.so")   # TTN_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define TTN_WG 1024            // threads of the dense (one-workgroup-per-train) kernels
+#ifndef TTN_WG
+#define TTN_WG 1024            // threads of the dense (one-workgroup-per-train) kernels (512 is supported for experiments)
+#endif
+#define TTN_NWAVES (TTN_WG / 64)
 #define TTN_MAX_D 64           // max chain length handled by the on-stack tables of the host API
 #define TTN_SV_NONE (-1)
 

@@ -10,7 +10,7 @@
 #include "ttn_common.h"
 #include <float.h>
 
-#define GEMM_BM 128
+#define GEMM_BM (32 * (TTN_NWAVES / 4))   // 4 wave columns x (nwaves/4) wave rows, 32x32 per wave
 #define GEMM_BN 128
 #define GEMM_BK 16
 #define GEMM_LD 144                      // LDS leading dimension (doubles): 144 % 32 == 16 spreads a half-wave's two k-rows over all banks
@@ -99,26 +99,27 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
     lds_f64* Bs = As + GEMM_BK * GEMM_LD;
     const bool a_kfast = minstride(A.c) < minstride(A.r);
     const bool b_kfast = minstride(B.r) < minstride(B.c);
-    // staging assignment: element e = tid + 1024*u, u = 0..3 of the 128 x 32 (A) and 32 x 128 (B) chunk
-    constexpr int NU = GEMM_BM * GEMM_BK / TTN_WG;      // 4
-    int ar[NU], akk[NU], bc[NU], bkk[NU];
+    // staging assignment: element e = tid + TTN_WG*u of the BM x BK (A) and BK x BN (B) chunk
+    constexpr int NUA = GEMM_BM * GEMM_BK / TTN_WG, NUB = GEMM_BN * GEMM_BK / TTN_WG;
+    int ar[NUA], akk[NUA], bc[NUB], bkk[NUB];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int u = 0; u < NUA; ++u) {
         const int e = tid + TTN_WG * u;
         if (a_kfast) { akk[u] = e & (GEMM_BK - 1); ar[u] = e / GEMM_BK; } else { ar[u] = e & (GEMM_BM - 1); akk[u] = e / GEMM_BM; }
+    }
+#pragma unroll
+    for (int u = 0; u < NUB; ++u) {
+        const int e = tid + TTN_WG * u;
         if (b_kfast) { bkk[u] = e & (GEMM_BK - 1); bc[u] = e / GEMM_BK; } else { bc[u] = e & (GEMM_BN - 1); bkk[u] = e / GEMM_BN; }
     }
     for (int m0 = 0; m0 < m; m0 += GEMM_BM) {
         for (int n0 = 0; n0 < n; n0 += GEMM_BN) {
-            long long aoff[NU], boff[NU];
-            bool aok[NU], bok[NU];
+            long long aoff[NUA], boff[NUB];
+            bool aok[NUA], bok[NUB];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                aok[u] = (m0 + ar[u]) < m;
-                bok[u] = (n0 + bc[u]) < n;
-                aoff[u] = aok[u] ? ix(A.r, m0 + ar[u]) : 0;
-                boff[u] = bok[u] ? ix(B.c, n0 + bc[u]) : 0;
-            }
+            for (int u = 0; u < NUA; ++u) { aok[u] = (m0 + ar[u]) < m; aoff[u] = aok[u] ? ix(A.r, m0 + ar[u]) : 0; }
+#pragma unroll
+            for (int u = 0; u < NUB; ++u) { bok[u] = (n0 + bc[u]) < n; boff[u] = bok[u] ? ix(B.c, n0 + bc[u]) : 0; }
             const bool live = (m0 + wr * 32 < m) && (n0 + wc * 32 < n);      // wave-uniform
             mfma_acc_t acc[2][2];
 #pragma unroll
@@ -126,28 +127,24 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
             // one chunk (GEMM_BK k-values) of global loads is kept in flight in registers while the MFMAs of the current one run
-            double av[NU], bv[NU];
+            double av[NUA], bv[NUB];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                av[u] = (aok[u] && akk[u] < k) ? A.p[aoff[u] + ix(A.c, akk[u])] : 0.0;
-                bv[u] = (bok[u] && bkk[u] < k) ? B.p[boff[u] + ix(B.r, bkk[u])] : 0.0;
-            }
+            for (int u = 0; u < NUA; ++u) av[u] = (aok[u] && akk[u] < k) ? A.p[aoff[u] + ix(A.c, akk[u])] : 0.0;
+#pragma unroll
+            for (int u = 0; u < NUB; ++u) bv[u] = (bok[u] && bkk[u] < k) ? B.p[boff[u] + ix(B.r, bkk[u])] : 0.0;
             for (int k0 = 0; k0 < k; k0 += GEMM_BK) {
                 __syncthreads();                       // the previous chunk has been consumed
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    As[akk[u] * GEMM_LD + ar[u]] = av[u];
-                    Bs[bkk[u] * GEMM_LD + bc[u]] = bv[u];
-                }
+                for (int u = 0; u < NUA; ++u) As[akk[u] * GEMM_LD + ar[u]] = av[u];
+#pragma unroll
+                for (int u = 0; u < NUB; ++u) Bs[bkk[u] * GEMM_LD + bc[u]] = bv[u];
                 __syncthreads();
                 const int k1 = k0 + GEMM_BK;
                 if (k1 < k) {
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        const int ga = k1 + akk[u], gb = k1 + bkk[u];
-                        av[u] = (aok[u] && ga < k) ? A.p[aoff[u] + ix(A.c, ga)] : 0.0;
-                        bv[u] = (bok[u] && gb < k) ? B.p[boff[u] + ix(B.r, gb)] : 0.0;
-                    }
+                    for (int u = 0; u < NUA; ++u) { const int ga = k1 + akk[u]; av[u] = (aok[u] && ga < k) ? A.p[aoff[u] + ix(A.c, ga)] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < NUB; ++u) { const int gb = k1 + bkk[u]; bv[u] = (bok[u] && gb < k) ? B.p[boff[u] + ix(B.r, gb)] : 0.0; }
                 }
                 if (live) {
 #pragma unroll
@@ -375,8 +372,7 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
                 scal = 1.0 / (alpha - beta);
             }
             if (tid == 0) { taus[r] = tau; scl[r] = scal; betas[r] = beta; }
-            const int i = r + 1 + wave;                   // wave w applies H_r to panel row r+1+w
-            if (tau != 0.0 && i < jb) {
+            for (int i = r + 1 + wave; tau != 0.0 && i < jb; i += nwaves) {   // wave w applies H_r to panel rows r+1+w, ...
                 double* ri = Pn + (long long)i * ldp;
                 double w = 0.0;
                 for (int c = r + 1 + lane; c < len; c += 64) w = fma(ri[c], row[c], w);
@@ -612,8 +608,8 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
                 const double cs = fast_rsqrt2(fma(t_, t_, 1.0));                                              \
                 const double sn = cs * t_;
         // ---- phase 0: pairs inside the blocks 2*wave and 2*wave+1 (both columns through LDS) ----
-        {
-            const int blk = 2 * wave + (grp >> 1);
+        for (int slot0 = wave; slot0 < (nbp + 1) / 2; slot0 += nwaves) {
+            const int blk = 2 * slot0 + (grp >> 1);
             if (blk < nb) {
                 const int c0 = 4 * blk, h = grp & 1;
 #pragma unroll
@@ -657,65 +653,81 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
         }
         __syncthreads();
         // ---- levels ----
+        constexpr int PPW = (16 + TTN_NWAVES - 1) / TTN_NWAVES;     // block pairs a wave owns per block round (nbp <= 32)
         for (int gs = nbp; gs >= 2; gs >>= 1) {
             const int h = gs >> 1;
-            const bool wact = wave < (nbp >> 1);
-            const int gam = wact ? wave / h : 0, aa = wact ? wave % h : 0;
-            const int ci = 4 * (gam * gs + aa) + grp;                       // stationary column of this lane group
-            const bool iact = wact && ci < p;
-            lds_f64* xi = X + ci * 128 + roff;
-            lds_f64x2 u[NT2];
-            double a = 0.0;
-            if (iact) {
-                a = nrm2[ci];
+            int gam[PPW], aa[PPW], ci[PPW];
+            bool iact[PPW];
+            lds_f64x2 u[PPW][NT2];
+            double an[PPW];
 #pragma unroll
-                for (int t = 0; t < NT2; ++t) u[t] = *(lds_v2*)(xi + 32 * t);
+            for (int q = 0; q < PPW; ++q) {
+                const int slot = wave + q * nwaves;
+                const bool wact = slot < (nbp >> 1);
+                gam[q] = wact ? slot / h : 0;
+                aa[q] = wact ? slot % h : 0;
+                ci[q] = 4 * (gam[q] * gs + aa[q]) + grp;                    // stationary column of this lane group
+                iact[q] = wact && ci[q] < p;
+                an[q] = 0.0;
+                if (iact[q]) {
+                    an[q] = nrm2[ci[q]];
+#pragma unroll
+                    for (int t = 0; t < NT2; ++t) u[q][t] = *(lds_v2*)(X + ci[q] * 128 + roff + 32 * t);
+                }
             }
             for (int r = 0; r < h; ++r) {
-                if (iact) {
-                    int mrot = aa + r; if (mrot >= h) mrot -= h;
-                    const int cjb = 4 * (gam * gs + h + mrot);
 #pragma unroll
-                    for (int sft = 0; sft < 4; ++sft) {
-                        const int cj = cjb + ((grp + sft) & 3);
-                        if (cj < p) {
-                            lds_f64* xj = X + cj * 128 + roff;
-                            const double b = nrm2[cj];
-                            lds_f64x2 v[NT2];
-                            double g0 = 0.0, g1 = 0.0;
+                for (int q = 0; q < PPW; ++q) {
+                    if (iact[q]) {
+                        int mrot = aa[q] + r; if (mrot >= h) mrot -= h;
+                        const int cjb = 4 * (gam[q] * gs + h + mrot);
 #pragma unroll
-                            for (int t = 0; t < NT2; ++t) {
-                                v[t] = *(lds_v2*)(xj + 32 * t);
-                                g0 = fma(u[t].x, v[t].x, g0);
-                                g1 = fma(u[t].y, v[t].y, g1);
-                            }
-                            const double g = row16_sum(g0 + g1);
-                            if ((a > aneg) && (b > aneg) && (g * g > tol2 * a * b)) {
-                                JROT_MATH
+                        for (int sft = 0; sft < 4; ++sft) {
+                            const int cj = cjb + ((grp + sft) & 3);
+                            if (cj < p) {
+                                lds_f64* xj = X + cj * 128 + roff;
+                                const double b = nrm2[cj];
+                                lds_f64x2 v[NT2];
+                                double g0 = 0.0, g1 = 0.0;
 #pragma unroll
                                 for (int t = 0; t < NT2; ++t) {
-                                    lds_f64x2 nu, nv;
-                                    nu.x = fma(cs, u[t].x, -sn * v[t].x);
-                                    nu.y = fma(cs, u[t].y, -sn * v[t].y);
-                                    nv.x = fma(sn, u[t].x, cs * v[t].x);
-                                    nv.y = fma(sn, u[t].y, cs * v[t].y);
-                                    u[t] = nu;
-                                    *(lds_v2*)(xj + 32 * t) = nv;
+                                    v[t] = *(lds_v2*)(xj + 32 * t);
+                                    g0 = fma(u[q][t].x, v[t].x, g0);
+                                    g1 = fma(u[q][t].y, v[t].y, g1);
                                 }
-                                if (sub == 0) nrm2[cj] = b + t_ * g;
-                                a = fmax(a - t_ * g, 0.0);
-                                rotated = 1;
+                                const double g = row16_sum(g0 + g1);
+                                const double a_ = an[q];
+                                if ((a_ > aneg) && (b > aneg) && (g * g > tol2 * a_ * b)) {
+                                    const double a = a_;
+                                    JROT_MATH
+#pragma unroll
+                                    for (int t = 0; t < NT2; ++t) {
+                                        lds_f64x2 nu, nv;
+                                        nu.x = fma(cs, u[q][t].x, -sn * v[t].x);
+                                        nu.y = fma(cs, u[q][t].y, -sn * v[t].y);
+                                        nv.x = fma(sn, u[q][t].x, cs * v[t].x);
+                                        nv.y = fma(sn, u[q][t].y, cs * v[t].y);
+                                        u[q][t] = nu;
+                                        *(lds_v2*)(xj + 32 * t) = nv;
+                                    }
+                                    if (sub == 0) nrm2[cj] = b + t_ * g;
+                                    an[q] = fmax(a - t_ * g, 0.0);
+                                    rotated = 1;
+                                }
                             }
+                            __builtin_amdgcn_wave_barrier();
                         }
-                        __builtin_amdgcn_wave_barrier();
                     }
                 }
                 __syncthreads();                                           // the moving blocks change hands
             }
-            if (iact) {
 #pragma unroll
-                for (int t = 0; t < NT2; ++t) *(lds_v2*)(xi + 32 * t) = u[t];
-                if (sub == 0) nrm2[ci] = a;
+            for (int q = 0; q < PPW; ++q) {
+                if (iact[q]) {
+#pragma unroll
+                    for (int t = 0; t < NT2; ++t) *(lds_v2*)(X + ci[q] * 128 + roff + 32 * t) = u[q][t];
+                    if (sub == 0) nrm2[ci[q]] = an[q];
+                }
             }
             __syncthreads();
         }
@@ -748,7 +760,8 @@ __device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* n
 // -------------------------------------------------------------------------------------------------
 __device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
     const int tid = threadIdx.x;
-    const int ti = tid & 127, tc = tid >> 7;             // row within a column, column group (8 columns per pass)
+    const int ti = tid & 127, tc = tid >> 7;             // row within a column, column group (TTN_WG/128 columns per pass)
+    constexpr int NCG = TTN_WG / 128;
     lds_f64* G = (lds_f64*)Gg;
     double dmax = 0.0;
     for (int j = tid; j < n; j += TTN_WG) dmax = fmax(dmax, G[j * 128 + j]);
@@ -767,13 +780,13 @@ __device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* 
         const double dinv = 1.0 / d;
         if (ti > j && ti < n) {
             const double lij = G[j * 128 + ti] * dinv;   // G[i][j] / d_j
-            for (int c = j + 1 + tc; c <= ti; c += 8)
+            for (int c = j + 1 + tc; c <= ti; c += NCG)
                 G[c * 128 + ti] = fma(-lij, G[j * 128 + c], G[c * 128 + ti]);
         }
         __syncthreads();
     }
     if (!bad) {
-        for (int c = tc; c < n; c += 8) {
+        for (int c = tc; c < n; c += NCG) {
             const double inv = 1.0 / sqrt(G[c * 128 + c]);
             __builtin_amdgcn_wave_barrier();
             if (ti > c && ti < n) G[c * 128 + ti] *= inv;
