@@ -143,6 +143,11 @@ int ttn_event_elapsed(int64_t slot_a, int64_t slot_b, float* ms);
 int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const double* B, double* C, double alpha, double beta,
                       int ta, int tb);
 
+/* micro-benchmark hook: the same workgroup GEMM on ONE compute unit, `reps` times back to back on device-resident zeros;
+ * cycles_out receives the shader-clock cycles (s_memtime) of the whole loop.  Used to price the dense phases against the
+ * per-CU fp64 MFMA peak (128 flop/clk/CU). */
+int ttn_bench_gemm(int64_t m, int64_t n, int64_t k, int ta, int tb, int64_t reps, int64_t* cycles_out);
+
 /* diagnostic: with TTN_PROF=1 in the environment ttn_compress records s_memtime ticks per phase
  * (merge, scale, LQ, Jacobi, sort/rank, split) for every train; out8 receives train b's 16 counters */
 int ttn_prof_get(int64_t b, int64_t* out8);

@@ -150,6 +150,8 @@ int ttn_init(int device) {
                                (int)(sizeof(double) * GEMM_LDS_TOTAL)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_selftest_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(double) * GEMM_LDS_TOTAL)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * GEMM_LDS_TOTAL)));
     g_device = device;
     g_init = true;
     return TTN_OK;
@@ -822,6 +824,30 @@ int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const do
     HIPCHK(hipMemcpyAsync(C, dC, sizeof(double) * m * n, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     hipFree(dA); hipFree(dB); hipFree(dC);
+    return TTN_OK;
+}
+
+int ttn_bench_gemm(int64_t m, int64_t n, int64_t k, int ta, int tb, int64_t reps, int64_t* cycles_out) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!cycles_out || m < 1 || n < 1 || k < 1 || reps < 1) return fail(TTN_ERR_ARG, "bad argument");
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    long long* dcy = nullptr;
+    HIPCHK(hipMalloc((void**)&dA, sizeof(double) * m * k));
+    HIPCHK(hipMalloc((void**)&dB, sizeof(double) * k * n));
+    HIPCHK(hipMalloc((void**)&dC, sizeof(double) * m * n));
+    HIPCHK(hipMalloc((void**)&dcy, sizeof(long long)));
+    HIPCHK(hipMemsetAsync(dA, 0, sizeof(double) * m * k, g_stream));
+    HIPCHK(hipMemsetAsync(dB, 0, sizeof(double) * k * n, g_stream));
+    HIPCHK(hipMemsetAsync(dC, 0, sizeof(double) * m * n, g_stream));
+    hipLaunchKernelGGL(k_bench_gemm, dim3(1), dim3(TTN_WG), sizeof(double) * GEMM_LDS_TOTAL, g_stream, (int)m, (int)n, (int)k,
+                       dA, dB, dC, ta, tb, (int)reps, dcy);
+    HIPCHK(hipGetLastError());
+    long long cy = 0;
+    HIPCHK(hipMemcpyAsync(&cy, dcy, sizeof(long long), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    *cycles_out = cy;
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dcy);
     return TTN_OK;
 }
 

@@ -550,35 +550,66 @@ __device__ __noinline__ int wg_jacobi_cols(int m, int p, double* X, int ldx, int
 typedef double lds_f64x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) lds_f64x2 lds_v2;
 
-// One sweep-loop instance for columns padded to 32*NT2 rows (NT2 = 1, 2, 4).  Lane `sub` of a 16-lane group owns the
-// row pairs {2*sub, 2*sub+1} + 32*t: every LDS access is a conflict-free 16-byte ds_read/write_b128 (the 16 lanes of
-// a group cover one 256-byte bank row).  Rows [m, 32*NT2) of every column must be zero on entry.
+// All-reduce over the 16 lanes of a Jacobi lane group, result in every lane of the group.  MUST be called in
+// wave-uniform control flow (the MFMA involves all 64 lanes).  The group of lane l is (l >> 2) & 3, i.e. the quad at
+// position g of each of the four 16-lane rows.  Two v_mfma_f64_4x4x4 against a matrix of ones do the reduction in the
+// matrix pipe: the instruction computes D_B[i][j] = sum_k A_B[i][k] with A_B[i][k] in lane B + 4i + 16k and D_B[i][j]
+// in lane 16B + 4i + j (layout measured on gfx950, scratch/mfma444_test.hip), so the first sums over k, the second
+// over B — together the 16 lanes with the same i.  Replaces 8 v_mov_dpp + 4 v_add_f64 + wait states on the VALU.
+__device__ inline double grp_sum(double v) {
+    const double s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(v, 1.0, 0.0, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(s1, 1.0, 0.0, 0, 0, 0);
+}
+// Hand a value to the previous lane group: lane l receives from lane l + 4 of its 16-lane row (row_ror:12), i.e. member
+// s of group g receives from member s of group (g + 1) mod 4.  Wave-uniform control flow only.
+__device__ inline double grp_from_next(double v) { return dpp_mov_f64<0x12C>(v); }
+
+// One sweep-loop instance.  A column is owned by a group of 16 lanes; a lane holds NT2 16-byte pieces of it, so the
+// instance reads 32*NT2 rows of every column (rows [m, 32*NT2) must be zero on entry).  A wave has 4 lane groups and
+// works on blocks of 4 columns.  Group g = (lane >> 2) & 3, member s = (lane & 3) + 4*(lane >> 4) (see grp_sum); the
+// member owns the row pairs {2s, 2s+1} + 32*t.
+//
+// What bounds the sweep (measured, profiles/README.md "Jacobi"): every rotation used to store its moving column to
+// LDS (1 KiB) and ds_write_b128 moves 79 B/clk per CU — 2.5 M stores x 13 clk = 2/3 of the Jacobi time, which neither
+// fewer VALU instructions (-20 %: no change), nor 8 lanes per column, nor 8 waves instead of 16 changed.  So:
+//   * the stationary column of each lane group stays in REGISTERS for a whole level;
+//   * the moving block is loaded from LDS once per block round and then handed from lane group to lane group in
+//     registers (16 v_mov_dpp per hand-over, VALU) — one LDS store per column and block round instead of four;
+//   * the 16-lane reductions run on the matrix pipe (grp_sum).
+// Control flow: which waves work is wave-uniform (branches); which lane groups of a working wave hold real columns
+// (only the last block of a p not divisible by 4 has phantom columns) is a MASK — phantom groups load whatever the
+// LDS holds, their dot product is discarded and they never write — so that grp_sum / grp_from_next run converged.
 template <int NT2>
 __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* flag, double* red,
                                   double tol_mult, double neg_mult, double* aneg_out) {
+    constexpr int G = 4;                                // lane groups per wave = columns per block
+    constexpr int CH = 32;                              // doubles per 16-byte-per-lane piece of a column
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
-    const int grp = lane >> 4, sub = lane & 15;
-    const int pe = p + (p & 1), half = pe >> 1;
+    const int grp = (lane >> 2) & 3;
+    const int sub = (lane & 3) | ((lane >> 4) << 2);
+    const int roff = 2 * sub;                           // row offset inside a piece
+#define JOFF(t) (roff + CH * (t))
     const double tol = tol_mult * sqrt((double)m) * DBL_EPSILON;
     const double tol2 = tol * tol;
-    const int kk = wave * 4 + grp;                      // pair slot of this 16-lane group
-    const int roff = 2 * sub;                           // row offset of this lane inside a 32-row chunk
     double aneg = 0.0;
     int sweep = 0;
     for (; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
         // ---- refresh the cached squared norms ----
         double amax = 0.0;
-        for (int c = kk; c < p; c += nwaves * 4) {
+        for (int cb = wave * G; cb < p; cb += nwaves * G) {
+            const int c = cb + grp;                      // < 128: inside the LDS image even when >= p
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
             for (int t = 0; t < NT2; ++t) {
-                const lds_f64x2 v = *(lds_v2*)(X + c * 128 + 32 * t + roff);
+                const lds_f64x2 v = *(lds_v2*)(X + c * 128 + JOFF(t));
                 a0 = fma(v.x, v.x, a0);
                 a1 = fma(v.y, v.y, a1);
             }
-            const double a = row16_sum(a0 + a1);
-            if (sub == 0) nrm2[c] = a;
-            amax = fmax(amax, a);
+            const double a = grp_sum(a0 + a1);
+            if (c < p) {
+                if (sub == 0) nrm2[c] = a;
+                amax = fmax(amax, a);
+            }
         }
         if (sweep == 0) {
             amax = wg_max(amax, red);
@@ -589,133 +620,140 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
         __syncthreads();
         int rotated = 0;
         // Block ordering.  The columns form nb blocks of 4 (nbp = nb rounded up to a power of two, phantom blocks idle).
-        //  phase 0: the 6 pairs inside every block;
+        //  phase 0: the 6 pairs inside every block (round-robin, both columns through LDS);
         //  then log2(nbp) LEVELS of a recursive tournament: at a level the blocks are split into groups of gs, each
         //  group into a stationary half and a moving half; in round r wave (group, a) rotates its stationary block
         //  against moving block (a + r) mod h — 16 cross pairs in 4 inner rounds, the 4 lane groups of the wave taking
         //  the 4 disjoint pairs of an inner round.  nbp-1 block rounds per sweep, every pair exactly once.
-        // The Jacobi is LDS-write-bandwidth bound (a rotation rewrites both columns), so the stationary column of each
-        // lane group is kept in REGISTERS for the whole level and only the moving columns go through LDS: half the LDS
-        // traffic of a plain round-robin.  Inner rounds need no workgroup barrier (one wave owns the block pair and its
-        // LDS operations execute in order); workgroup barriers: one per block round.
-        const int nb = (p + 3) >> 2;
+        // Workgroup barriers: one per block round (the moving blocks change hands).
+        const int nb = (p + G - 1) / G;
         int nbp = 1;
         while (nbp < nb) nbp <<= 1;
+// t = tan(theta) of the Jacobi rotation from d = b - a, h = 2g:  t = sign(d) h / (|d| + sqrt(d^2 + h^2)); raw
+// v_sqrt/v_rcp seeds are enough for t (it only sets the speed of convergence), c = rsqrt(1 + t^2) gets two Newton steps
+// so that c^2 + s^2 = 1 to rounding (that is what makes every applied rotation orthogonal, i.e. backward stable).
 #define JROT_MATH                                                                                             \
-                const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);                                  \
-                const double sq = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));                                \
-                const double t_ = copysign(__builtin_amdgcn_rcp(fabs(zeta) + sq), zeta);                      \
-                const double cs = fast_rsqrt2(fma(t_, t_, 1.0));                                              \
+                const double dd_ = b - a, hh_ = g + g;                                                        \
+                const double hyp_ = __builtin_amdgcn_sqrt(fma(dd_, dd_, hh_ * hh_));                          \
+                const double t_ = copysign(hh_ * __builtin_amdgcn_rcp(fabs(dd_) + hyp_), hh_ * dd_ );         \
+                const double w_ = fma(t_, t_, 1.0);                                                           \
+                const double cs = fast_rsqrt2(w_);                                                            \
                 const double sn = cs * t_;
-        // ---- phase 0: pairs inside the blocks 2*wave and 2*wave+1 (both columns through LDS) ----
-        for (int slot0 = wave; slot0 < (nbp + 1) / 2; slot0 += nwaves) {
-            const int blk = 2 * slot0 + (grp >> 1);
-            if (blk < nb) {
-                const int c0 = 4 * blk, h = grp & 1;
+        // ---- phase 0: pairs inside the blocks 2*slot and 2*slot+1 (circle method: local column 3 stays put) ----
+        for (int slot0 = wave; 2 * slot0 < nb; slot0 += nwaves) {
+            const int blk = 2 * slot0 + (grp >> 1), hq = grp & 1;
+            const int c0 = G * blk;
 #pragma unroll
-                for (int rr = 0; rr < 3; ++rr) {
-                    // rr = 0: (0,1),(2,3)   rr = 1: (0,2),(1,3)   rr = 2: (0,3),(1,2)
-                    const int i = c0 + ((rr == 0) ? 2 * h : h);
-                    const int j = c0 + ((rr == 0) ? 2 * h + 1 : ((rr == 1) ? h + 2 : 3 - h));
-                    if (i < p && j < p) {
-                        lds_f64* xi = X + i * 128 + roff;
-                        lds_f64* xj = X + j * 128 + roff;
-                        const double a = nrm2[i], b = nrm2[j];
-                        lds_f64x2 u[NT2], v[NT2];
-                        double g0 = 0.0, g1 = 0.0;
+            for (int rr = 0; rr < G - 1; ++rr) {
+                const int li = (hq == 0) ? G - 1 : (rr + hq) % (G - 1);
+                const int lj = (hq == 0) ? rr : (rr + G - 1 - hq) % (G - 1);
+                const int i = (c0 + (li < lj ? li : lj)) & 127, j = (c0 + (li < lj ? lj : li)) & 127;
+                const bool act = j < p && blk < nb;
+                lds_f64* xi = X + i * 128;
+                lds_f64* xj = X + j * 128;
+                const double a = nrm2[i], b = nrm2[j];
+                lds_f64x2 u[NT2], v[NT2];
+                double g0 = 0.0, g1 = 0.0;
 #pragma unroll
-                        for (int t = 0; t < NT2; ++t) {
-                            u[t] = *(lds_v2*)(xi + 32 * t);
-                            v[t] = *(lds_v2*)(xj + 32 * t);
-                            g0 = fma(u[t].x, v[t].x, g0);
-                            g1 = fma(u[t].y, v[t].y, g1);
-                        }
-                        const double g = row16_sum(g0 + g1);
-                        if ((a > aneg) && (b > aneg) && (g * g > tol2 * a * b)) {
-                            JROT_MATH
-#pragma unroll
-                            for (int t = 0; t < NT2; ++t) {
-                                lds_f64x2 nu, nv;
-                                nu.x = fma(cs, u[t].x, -sn * v[t].x);
-                                nu.y = fma(cs, u[t].y, -sn * v[t].y);
-                                nv.x = fma(sn, u[t].x, cs * v[t].x);
-                                nv.y = fma(sn, u[t].y, cs * v[t].y);
-                                *(lds_v2*)(xi + 32 * t) = nu;
-                                *(lds_v2*)(xj + 32 * t) = nv;
-                            }
-                            if (sub == 0) { nrm2[i] = fmax(a - t_ * g, 0.0); nrm2[j] = b + t_ * g; }
-                            rotated = 1;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                for (int t = 0; t < NT2; ++t) {
+                    u[t] = *(lds_v2*)(xi + JOFF(t));
+                    v[t] = *(lds_v2*)(xj + JOFF(t));
+                    g0 = fma(u[t].x, v[t].x, g0);
+                    g1 = fma(u[t].y, v[t].y, g1);
                 }
+                const double g = grp_sum(g0 + g1);
+                if (act && (a > aneg) && (b > aneg) && (g * g > tol2 * a * b)) {
+                    JROT_MATH
+#pragma unroll
+                    for (int t = 0; t < NT2; ++t) {
+                        lds_f64x2 nu, nv;
+                        nu.x = fma(cs, u[t].x, -sn * v[t].x);
+                        nu.y = fma(cs, u[t].y, -sn * v[t].y);
+                        nv.x = fma(sn, u[t].x, cs * v[t].x);
+                        nv.y = fma(sn, u[t].y, cs * v[t].y);
+                        *(lds_v2*)(xi + JOFF(t)) = nu;
+                        *(lds_v2*)(xj + JOFF(t)) = nv;
+                    }
+                    if (sub == 0) { nrm2[i] = fmax(a - t_ * g, 0.0); nrm2[j] = b + t_ * g; }
+                    rotated = 1;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();
         // ---- levels ----
-        constexpr int PPW = (16 + TTN_NWAVES - 1) / TTN_NWAVES;     // block pairs a wave owns per block round (nbp <= 32)
+        constexpr int PPW = (16 + TTN_NWAVES - 1) / TTN_NWAVES;         // block pairs a wave owns per block round (p <= 128)
         for (int gs = nbp; gs >= 2; gs >>= 1) {
             const int h = gs >> 1;
             int gam[PPW], aa[PPW], ci[PPW];
-            bool iact[PPW];
+            bool wact[PPW], iact[PPW];
             lds_f64x2 u[PPW][NT2];
             double an[PPW];
 #pragma unroll
             for (int q = 0; q < PPW; ++q) {
                 const int slot = wave + q * nwaves;
-                const bool wact = slot < (nbp >> 1);
-                gam[q] = wact ? slot / h : 0;
-                aa[q] = wact ? slot % h : 0;
-                ci[q] = 4 * (gam[q] * gs + aa[q]) + grp;                    // stationary column of this lane group
-                iact[q] = wact && ci[q] < p;
-                an[q] = 0.0;
-                if (iact[q]) {
-                    an[q] = nrm2[ci[q]];
+                wact[q] = slot < (nbp >> 1);                                // wave-uniform
+                gam[q] = wact[q] ? slot / h : 0;
+                aa[q] = wact[q] ? slot % h : 0;
+                ci[q] = (G * (gam[q] * gs + aa[q]) + grp) & 127;            // stationary column of this lane group
+                iact[q] = wact[q] && ci[q] < p;
+                an[q] = nrm2[ci[q]];
 #pragma unroll
-                    for (int t = 0; t < NT2; ++t) u[q][t] = *(lds_v2*)(X + ci[q] * 128 + roff + 32 * t);
-                }
+                for (int t = 0; t < NT2; ++t) u[q][t] = *(lds_v2*)(X + ci[q] * 128 + JOFF(t));
             }
             for (int r = 0; r < h; ++r) {
 #pragma unroll
                 for (int q = 0; q < PPW; ++q) {
-                    if (iact[q]) {
+                    if (wact[q]) {
                         int mrot = aa[q] + r; if (mrot >= h) mrot -= h;
-                        const int cjb = 4 * (gam[q] * gs + h + mrot);
+                        const int cjb = G * (gam[q] * gs + h + mrot);
+                        // the moving column this lane group starts with; it then takes the next group's column each inner round
+                        const int cj0 = (cjb + grp) & 127;
+                        lds_f64x2 v[NT2];
 #pragma unroll
-                        for (int sft = 0; sft < 4; ++sft) {
-                            const int cj = cjb + ((grp + sft) & 3);
-                            if (cj < p) {
-                                lds_f64* xj = X + cj * 128 + roff;
-                                const double b = nrm2[cj];
-                                lds_f64x2 v[NT2];
-                                double g0 = 0.0, g1 = 0.0;
+                        for (int t = 0; t < NT2; ++t) v[t] = *(lds_v2*)(X + cj0 * 128 + JOFF(t));
+                        double b = nrm2[cj0];
+                        int dirty = 0;
+#pragma unroll
+                        for (int sft = 0; sft < G; ++sft) {
+                            const int cj = (cjb + ((grp + sft) & (G - 1))) & 127;
+                            const bool act = iact[q] && cj < p;
+                            double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+                            for (int t = 0; t < NT2; ++t) {
+                                g0 = fma(u[q][t].x, v[t].x, g0);
+                                g1 = fma(u[q][t].y, v[t].y, g1);
+                            }
+                            const double g = grp_sum(g0 + g1);
+                            const double a = an[q];
+                            if (act && (a > aneg) && (b > aneg) && (g * g > tol2 * a * b)) {
+                                JROT_MATH
+                                const double ic = w_ * cs;                 // 1/c
+                                // u' = c (u - t v);  v' = t u' + v / c  — both in place (v_fmac / v_mul on their own registers)
 #pragma unroll
                                 for (int t = 0; t < NT2; ++t) {
-                                    v[t] = *(lds_v2*)(xj + 32 * t);
-                                    g0 = fma(u[q][t].x, v[t].x, g0);
-                                    g1 = fma(u[q][t].y, v[t].y, g1);
+                                    u[q][t].x = cs * fma(-t_, v[t].x, u[q][t].x);
+                                    u[q][t].y = cs * fma(-t_, v[t].y, u[q][t].y);
+                                    v[t].x = fma(t_, u[q][t].x, ic * v[t].x);
+                                    v[t].y = fma(t_, u[q][t].y, ic * v[t].y);
                                 }
-                                const double g = row16_sum(g0 + g1);
-                                const double a_ = an[q];
-                                if ((a_ > aneg) && (b > aneg) && (g * g > tol2 * a_ * b)) {
-                                    const double a = a_;
-                                    JROT_MATH
-#pragma unroll
-                                    for (int t = 0; t < NT2; ++t) {
-                                        lds_f64x2 nu, nv;
-                                        nu.x = fma(cs, u[q][t].x, -sn * v[t].x);
-                                        nu.y = fma(cs, u[q][t].y, -sn * v[t].y);
-                                        nv.x = fma(sn, u[q][t].x, cs * v[t].x);
-                                        nv.y = fma(sn, u[q][t].y, cs * v[t].y);
-                                        u[q][t] = nu;
-                                        *(lds_v2*)(xj + 32 * t) = nv;
-                                    }
-                                    if (sub == 0) nrm2[cj] = b + t_ * g;
-                                    an[q] = fmax(a - t_ * g, 0.0);
-                                    rotated = 1;
-                                }
+                                b = b + t_ * g;
+                                an[q] = fmax(a - t_ * g, 0.0);
+                                dirty = 1;
                             }
-                            __builtin_amdgcn_wave_barrier();
+                            if (sft < G - 1) {
+#pragma unroll
+                                for (int t = 0; t < NT2; ++t) { v[t].x = grp_from_next(v[t].x); v[t].y = grp_from_next(v[t].y); }
+                                b = grp_from_next(b);
+                                dirty = __builtin_amdgcn_update_dpp(0, dirty, 0x12C, 0xF, 0xF, true);
+                            }
+                        }
+                        const int cjl = (cjb + ((grp + G - 1) & (G - 1))) & 127;     // the column this group ends up with
+                        if (dirty && cjl < p) {
+#pragma unroll
+                            for (int t = 0; t < NT2; ++t) *(lds_v2*)(X + cjl * 128 + JOFF(t)) = v[t];
+                            if (sub == 0) nrm2[cjl] = b;
+                            rotated = 1;
                         }
                     }
                 }
@@ -725,14 +763,15 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
             for (int q = 0; q < PPW; ++q) {
                 if (iact[q]) {
 #pragma unroll
-                    for (int t = 0; t < NT2; ++t) *(lds_v2*)(X + ci[q] * 128 + roff + 32 * t) = u[q][t];
+                    for (int t = 0; t < NT2; ++t) *(lds_v2*)(X + ci[q] * 128 + JOFF(t)) = u[q][t];
                     if (sub == 0) nrm2[ci[q]] = an[q];
                 }
             }
             __syncthreads();
         }
 #undef JROT_MATH
-        if (rotated) atomicOr(flag, 1);
+#undef JOFF
+        if (rotated) *flag = 1;
         __syncthreads();
         const int any = *flag;
         __syncthreads();
@@ -742,7 +781,7 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
 }
 
 // Fast path of the one-sided Jacobi: p <= 128 columns of length m <= 128 in LDS, leading dimension 128; rows
-// [m, roundup32(m)) of every column must be ZERO (the caller pads).  See jacobi_lds128_body.
+// [m, 128) of every column must be ZERO (the caller pads).  See jacobi_lds128_body.
 __device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* nrm2g, int* flag, double* red,
                                              double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
     if (p < 2) { if (threadIdx.x == 0) *aneg_out = 0.0; __syncthreads(); return 0; }
@@ -1254,4 +1293,17 @@ __global__ void __launch_bounds__(TTN_WG) k_selftest_gemm(int m, int n, int k, d
     const View Av = ta ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));     // ta: A stored k x m
     const View Bv = tb ? mkview(B, plain(1), plain(k)) : mkview(B, plain(n), plain(1));     // tb: B stored n x k
     wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), alpha, beta, lds);
+}
+
+__global__ void __launch_bounds__(TTN_WG) k_bench_gemm(int m, int n, int k, double* A, double* B, double* C, int ta, int tb, int reps,
+                                                      long long* cycles) {
+    extern __shared__ double lds[];
+    const View Av = ta ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));
+    const View Bv = tb ? mkview(B, plain(1), plain(k)) : mkview(B, plain(n), plain(1));
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < reps; ++r) wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), 1.0, 0.0, lds);
+    __syncthreads();
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) *cycles = t1 - t0;
 }

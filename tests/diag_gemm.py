@@ -1,0 +1,19 @@
+"""Diagnostic (not a test): cycles of the workgroup GEMM on one CU for the shapes of the C3 sweep, against the
+fp64 MFMA peak of one CU (128 flop/clk)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ttn_amd as T
+T.ensure_init(0)
+L = T._lib.lib()
+shapes = [  # (m, n, k, ta, tb, what)
+    (128, 384, 192, 0, 0, "merge L->R"), (128, 128, 384, 0, 1, "gram M M^T"), (64, 384, 128, 1, 0, "split Vt = U^T M"),
+    (128, 128, 64, 0, 0, "merge R->L"), (64, 64, 128, 1, 0, "gram A^T A (F)"), (64, 64, 64, 0, 0, "small 64^3"),
+    (128, 128, 128, 0, 0, "128^3"), (128, 64, 128, 0, 0, "U = X W"), (192, 192, 128, 0, 0, "dot-like"),
+]
+for m, n, k, ta, tb, what in shapes:
+    reps = 20
+    cy = C.c_int64()
+    T._lib.check(L.ttn_bench_gemm(m, n, k, ta, tb, reps, C.byref(cy)))
+    per = cy.value / reps
+    flop = 2.0 * m * n * k
+    print(f"{what:20s} {m:4d}x{n:4d}x{k:4d} ta={ta} tb={tb}: {per:10.0f} clk  {flop/per:6.1f} flop/clk  ({100*flop/per/128:5.1f}% of CU peak)")
