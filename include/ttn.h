@@ -147,6 +147,9 @@ int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const do
  * cycles_out receives the shader-clock cycles (s_memtime) of the whole loop.  Used to price the dense phases against the
  * per-CU fp64 MFMA peak (128 flop/clk/CU). */
 int ttn_bench_gemm(int64_t m, int64_t n, int64_t k, int ta, int tb, int64_t reps, int64_t* cycles_out);
+/* same for the LDS-resident building blocks on an n x n SPD test matrix (n <= 128): what = 0 set-up only, 1 set-up + Cholesky,
+ * 2 set-up + one-sided Jacobi of the matrix columns; sweeps_out (may be NULL) receives the Jacobi sweep count of the last rep */
+int ttn_bench_lds(int what, int64_t n, int64_t reps, int64_t* cycles_out, int64_t* sweeps_out);
 
 /* diagnostic: with TTN_PROF=1 in the environment ttn_compress records s_memtime ticks per phase
  * (merge, scale, LQ, Jacobi, sort/rank, split) for every train; out8 receives train b's 16 counters */

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ttn_sv_get": (C.c_int, [handle, i64, i64, p_f64, i64, p_i64]),
     "ttn_timer_begin": (C.c_int, []),
     "ttn_timer_end": (C.c_int, [C.POINTER(C.c_float)]),
+    "ttn_bench_lds": (C.c_int, [C.c_int, i64, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ttn_bench_gemm": (C.c_int, [i64, i64, i64, C.c_int, C.c_int, i64, C.POINTER(C.c_int64)]),
     "ttn_selftest_gemm": (C.c_int, [i64, i64, i64, p_f64, p_f64, p_f64, C.c_double, C.c_double, C.c_int, C.c_int]),
     "ttn_prof_get": (C.c_int, [i64, p_i64]),

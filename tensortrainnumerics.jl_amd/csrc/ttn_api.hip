@@ -152,6 +152,8 @@ int ttn_init(int device) {
                                (int)(sizeof(double) * GEMM_LDS_TOTAL)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(double) * GEMM_LDS_TOTAL)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(COMPRESS_LDS_BYTES)));
     g_device = device;
     g_init = true;
     return TTN_OK;
@@ -848,6 +850,23 @@ int ttn_bench_gemm(int64_t m, int64_t n, int64_t k, int ta, int tb, int64_t reps
     HIPCHK(hipStreamSynchronize(g_stream));
     *cycles_out = cy;
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dcy);
+    return TTN_OK;
+}
+
+int ttn_bench_lds(int what, int64_t n, int64_t reps, int64_t* cycles_out, int64_t* sweeps_out) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!cycles_out || n < 1 || n > 128 || reps < 1 || what < 0 || what > 2) return fail(TTN_ERR_ARG, "bad argument");
+    long long* dout = nullptr;
+    HIPCHK(hipMalloc((void**)&dout, 2 * sizeof(long long)));
+    hipLaunchKernelGGL(k_bench_lds, dim3(1), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, what, (int)n, (int)reps, dout);
+    HIPCHK(hipGetLastError());
+    long long h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, dout, sizeof(h), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    *cycles_out = h[0];
+    if (sweeps_out) *sweeps_out = h[1];
+    hipFree(dout);
     return TTN_OK;
 }
 

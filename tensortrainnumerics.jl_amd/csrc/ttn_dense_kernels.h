@@ -13,9 +13,16 @@
 #define GEMM_BM (32 * (TTN_NWAVES / 4))   // 4 wave columns x (nwaves/4) wave rows, 32x32 per wave
 #define GEMM_BN 128
 #define GEMM_BK 16
-#define GEMM_LD 144                      // LDS leading dimension (doubles): 144 % 32 == 16 spreads a half-wave's two k-rows over all banks
-#define GEMM_TILE_DOUBLES (2 * GEMM_BK * GEMM_LD)   // LDS used by the tiled (big) GEMM
-#define GEMM_LDS_DOUBLES (128 * 128)               // LDS region every GEMM may use (the one-shot small GEMM uses all of it)
+// LDS leading dimension (doubles) of the staged chunks, 145 = 17 mod 32.  Two access patterns meet here:
+//  * a k-fast operand is staged by 16 lanes that walk k (coalesced global reads) and store to As[kk*LD + r]: an even LD
+//    puts all 16 stores on ONE bank pair (16-way conflict: measured 49 % of the MFMA peak with LD = 144, stores alone
+//    cost 13 points); with LD odd, 2*kk*LD mod 32 = 2*kk: conflict free;
+//  * the MFMA fragment reads take two k-rows per 32-lane half (ds_read_b64, 64 banks): LD*8 mod 256 = 136 puts the second
+//    row 2 banks short of the other half: one 2-way conflict per read instead of none.
+#define GEMM_LD 145
+#define GEMM_TILE_DOUBLES (2 * GEMM_BK * GEMM_LD)   // one LDS stage (A and B chunk) of the tiled (big) GEMM; it keeps two
+#define GEMM_LDS_DOUBLES (128 * 128 + 512)         // LDS region every GEMM may use (the one-shot small GEMM uses all of it): the 128x128
+                                                   // Jacobi image + room for the odd leading dimensions of a 64x64x128 one-shot product
 #define QR_NB 16                         // Householder panel width
 #define JACOBI_MAX_SWEEPS 40
 
@@ -72,8 +79,19 @@ struct GemmDesc {
     View A, B, C;
     double alpha, beta;
 };
-#define GEMM_DESC_DOUBLES 32            // sizeof(GemmDesc) = 200 bytes, kept right behind the LDS tiles
+// Behind the LDS tiles: the descriptor (sizeof(GemmDesc) = 200 bytes, 32 doubles reserved) and the OFFSET TABLES.
+// Operands are 2-level strided Views, so an element address costs two integer divisions; a GEMM evaluates ix() once per
+// row / column / k index into these tables and the staging loops only add table entries.
+#define GEMM_TAB_ENTRIES 1536
+#define GEMM_KSLAB (GEMM_TAB_ENTRIES / 2)        // k indices tabulated at a time by the tiled GEMM (A and B tables)
+#define GEMM_DESC_DOUBLES (32 + GEMM_TAB_ENTRIES)
 #define GEMM_LDS_TOTAL (GEMM_LDS_DOUBLES + GEMM_DESC_DOUBLES)
+typedef __attribute__((address_space(3))) long long lds_i64;
+// GEMM A/B operands always live in global memory.  Loading them through the generic `double*` of a View makes the
+// compiler emit flat_load, which counts on lgkmcnt as well as vmcnt — every `s_waitcnt lgkmcnt(0)` in front of an MFMA
+// group (meant for the LDS fragment reads) then also waits for the global loads of the NEXT chunk: measured 49 % -> 7x %
+// of the per-CU MFMA peak for the tiled GEMM once the loads are global_load.
+typedef const __attribute__((address_space(1))) double gmem_f64;
 
 // The body is deliberately NOT inlined (17 call sites) and takes its operands through a descriptor in LDS: only two
 // pointers cross the call boundary.
@@ -95,8 +113,10 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 15, lk = lane >> 4;
-    lds_f64* As = (lds_f64*)lds;
-    lds_f64* Bs = As + GEMM_BK * GEMM_LD;
+    gmem_f64* Ag = (gmem_f64*)A.p;
+    gmem_f64* Bg = (gmem_f64*)B.p;
+    lds_i64* tabA = (lds_i64*)(lds + GEMM_LDS_DOUBLES + 32);      // ix(A.c, slab0 + j), j < GEMM_KSLAB
+    lds_i64* tabB = tabA + GEMM_KSLAB;                            // ix(B.r, slab0 + j)
     const bool a_kfast = minstride(A.c) < minstride(A.r);
     const bool b_kfast = minstride(B.r) < minstride(B.c);
     // staging assignment: element e = tid + TTN_WG*u of the BM x BK (A) and BK x BN (B) chunk
@@ -112,6 +132,8 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
         const int e = tid + TTN_WG * u;
         if (b_kfast) { bkk[u] = e & (GEMM_BK - 1); bc[u] = e / GEMM_BK; } else { bc[u] = e & (GEMM_BN - 1); bkk[u] = e / GEMM_BN; }
     }
+    const int nch = (k + GEMM_BK - 1) / GEMM_BK;
+    int slab0 = -1;                                               // first k index the tables currently hold
     for (int m0 = 0; m0 < m; m0 += GEMM_BM) {
         for (int n0 = 0; n0 < n; n0 += GEMM_BN) {
             long long aoff[NUA], boff[NUB];
@@ -126,39 +148,98 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
-            // one chunk (GEMM_BK k-values) of global loads is kept in flight in registers while the MFMAs of the current one run
             double av[NUA], bv[NUB];
-#pragma unroll
-            for (int u = 0; u < NUA; ++u) av[u] = (aok[u] && akk[u] < k) ? A.p[aoff[u] + ix(A.c, akk[u])] : 0.0;
-#pragma unroll
-            for (int u = 0; u < NUB; ++u) bv[u] = (bok[u] && bkk[u] < k) ? B.p[boff[u] + ix(B.r, bkk[u])] : 0.0;
-            for (int k0 = 0; k0 < k; k0 += GEMM_BK) {
-                __syncthreads();                       // the previous chunk has been consumed
-#pragma unroll
-                for (int u = 0; u < NUA; ++u) As[akk[u] * GEMM_LD + ar[u]] = av[u];
-#pragma unroll
-                for (int u = 0; u < NUB; ++u) Bs[bkk[u] * GEMM_LD + bc[u]] = bv[u];
-                __syncthreads();
-                const int k1 = k0 + GEMM_BK;
-                if (k1 < k) {
-#pragma unroll
-                    for (int u = 0; u < NUA; ++u) { const int ga = k1 + akk[u]; av[u] = (aok[u] && ga < k) ? A.p[aoff[u] + ix(A.c, ga)] : 0.0; }
-#pragma unroll
-                    for (int u = 0; u < NUB; ++u) { const int gb = k1 + bkk[u]; bv[u] = (bok[u] && gb < k) ? B.p[boff[u] + ix(B.r, gb)] : 0.0; }
-                }
-                if (live) {
-#pragma unroll
-                    for (int t = 0; t < GEMM_BK / 4; ++t) {
-                        const int kr = (4 * t + lk) * GEMM_LD;
-                        const double a0 = As[kr + wr * 32 + li], a1 = As[kr + wr * 32 + 16 + li];
-                        const double b0 = Bs[kr + wc * 32 + li], b1 = Bs[kr + wc * 32 + 16 + li];
-                        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-                    }
-                }
+            // Software pipeline over the K chunks, two LDS stages, ONE barrier per chunk:
+            //   iteration c:  MFMAs of chunk c (stage c&1) | registers (chunk c+1) -> stage (c+1)&1 | global loads of chunk c+2
+#define GEMM_FILL_TAB(K0)                                                                                       \
+            {                                                                                                   \
+                __syncthreads();                                                                                \
+                slab0 = (K0);                                                                                   \
+                for (int j = tid; j < GEMM_KSLAB; j += TTN_WG) {                                                \
+                    const int kk = slab0 + j;                                                                   \
+                    tabA[j] = (kk < k) ? ix(A.c, kk) : 0;                                                       \
+                    tabB[j] = (kk < k) ? ix(B.r, kk) : 0;                                                       \
+                }                                                                                               \
+                __syncthreads();                                                                                \
             }
+#define GEMM_LOAD(K0)  /* branch-free: out-of-range elements read element 0 of the operand and are then zeroed */        \
+            {                                                                                                   \
+                long long oa_[NUA], ob_[NUB];                                                                   \
+                bool va_[NUA], vb_[NUB];                                                                        \
+                _Pragma("unroll") for (int u = 0; u < NUA; ++u) {                                               \
+                    const int ga = (K0) + akk[u];                                                               \
+                    va_[u] = aok[u] && ga < k;                                                                  \
+                    oa_[u] = va_[u] ? aoff[u] + tabA[ga - slab0] : 0;                                           \
+                }                                                                                               \
+                _Pragma("unroll") for (int u = 0; u < NUB; ++u) {                                               \
+                    const int gb = (K0) + bkk[u];                                                               \
+                    vb_[u] = bok[u] && gb < k;                                                                  \
+                    ob_[u] = vb_[u] ? boff[u] + tabB[gb - slab0] : 0;                                           \
+                }                                                                                               \
+                _Pragma("unroll") for (int u = 0; u < NUA; ++u) av[u] = Ag[oa_[u]];                             \
+                _Pragma("unroll") for (int u = 0; u < NUB; ++u) bv[u] = Bg[ob_[u]];                             \
+                _Pragma("unroll") for (int u = 0; u < NUA; ++u) av[u] = va_[u] ? av[u] : 0.0;                   \
+                _Pragma("unroll") for (int u = 0; u < NUB; ++u) bv[u] = vb_[u] ? bv[u] : 0.0;                   \
+            }
+#define GEMM_STORE(STG)                                                                                         \
+            {                                                                                                   \
+                lds_f64* As_ = (lds_f64*)lds + (STG) * GEMM_TILE_DOUBLES;                                       \
+                lds_f64* Bs_ = As_ + GEMM_BK * GEMM_LD;                                                         \
+                _Pragma("unroll") for (int u = 0; u < NUA; ++u) As_[akk[u] * GEMM_LD + ar[u]] = av[u];          \
+                _Pragma("unroll") for (int u = 0; u < NUB; ++u) Bs_[bkk[u] * GEMM_LD + bc[u]] = bv[u];          \
+            }
+            if (slab0 != 0) GEMM_FILL_TAB(0)
+            else __syncthreads();                      // the previous tile's MFMAs have consumed both stages
+            GEMM_LOAD(0)
+            GEMM_STORE(0)
+            if (nch > 1) {
+                if (GEMM_BK >= slab0 + GEMM_KSLAB) GEMM_FILL_TAB(GEMM_BK)
+                GEMM_LOAD(GEMM_BK)
+            }
+            __syncthreads();
+            for (int c = 0; c < nch; ++c) {
+                // The staging work of the other chunks is placed BETWEEN this wave's MFMA groups: an MFMA occupies the
+                // matrix pipe for 64 clk, so the VALU/LDS/global instructions issued behind it run under the MFMAs of
+                // the SIMD's other waves instead of after them (the waves run in lockstep from barrier to barrier).
+                lds_f64* As = (lds_f64*)lds + (c & 1) * GEMM_TILE_DOUBLES;
+                lds_f64* Bs = As + GEMM_BK * GEMM_LD;
+#ifdef GEMM_EXP_NOLDS
+#define GEMM_EXP_READS const double a0 = alpha + kr, a1 = alpha - kr, b0 = beta + kr, b1 = beta - kr;
+#else
+#define GEMM_EXP_READS const double a0 = As[kr + wr * 32 + li], a1 = As[kr + wr * 32 + 16 + li]; const double b0 = Bs[kr + wc * 32 + li], b1 = Bs[kr + wc * 32 + 16 + li];
+#endif
+#define GEMM_MFMA_STEP(T)                                                                                       \
+                if (live) {                                                                                     \
+                    const int kr = (4 * (T) + lk) * GEMM_LD;                                                    \
+                    GEMM_EXP_READS                                                                              \
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);               \
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);               \
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);               \
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);               \
+                }
+                GEMM_MFMA_STEP(0)
+#if !defined(GEMM_EXP_NOSTAGE) && !defined(GEMM_EXP_NOSTORE)
+                if (c + 1 < nch) GEMM_STORE((c + 1) & 1)
+#endif
+                GEMM_MFMA_STEP(1)
+#if !defined(GEMM_EXP_NOSTAGE) && !defined(GEMM_EXP_NOLOAD)
+                if (c + 2 < nch)
+#else
+                if (false)
+#endif
+                {
+                    const int k2 = (c + 2) * GEMM_BK;
+                    if (k2 >= slab0 + GEMM_KSLAB) GEMM_FILL_TAB(k2)       // workgroup-uniform; rare (k > GEMM_KSLAB)
+                    GEMM_LOAD(k2)
+                }
+                GEMM_MFMA_STEP(2)
+                GEMM_MFMA_STEP(3)
+#undef GEMM_MFMA_STEP
+                __syncthreads();
+            }
+#undef GEMM_FILL_TAB
+#undef GEMM_LOAD
+#undef GEMM_STORE
             if (live) {
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
@@ -189,7 +270,8 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
 // are latency bound: a 64x64x128 product is 1 Mflop), one barrier, k/4 MFMAs per tile, store.  Small register
 // footprint on purpose (8 accumulator doubles per tile): the factored route issues ten of these per bond step.
 // -------------------------------------------------------------------------------------------------
-__device__ inline int small_ld(int x) { const int t = (x + 15) & ~15; return ((t & 31) == 16) ? t : t + 16; }   // == 16 mod 32
+__device__ inline int small_ld(int x) { const int t = (x + 15) & ~15; return (((t & 31) == 16) ? t : t + 16) + 1; }   // == 17 mod 32 (see GEMM_LD)
+__device__ inline int tight_ld(int x) { return ((x + 15) & ~15) + 1; }                                             // odd: conflict-free k-fast stores
 
 __device__ __noinline__ void wg_gemm_small_impl(const GemmDesc* dsc, double* lds) {
     const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
@@ -197,23 +279,54 @@ __device__ __noinline__ void wg_gemm_small_impl(const GemmDesc* dsc, double* lds
     const double alpha = unif64(dsc->alpha), beta = unif64(dsc->beta);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    // dsc->pad = 1: leading dimensions == 16 mod 32 (conflict-free fragment reads); 0: tight (2-way conflicts, fits more)
-    const int lda = uni32(dsc->pad) ? small_ld(m) : ((m + 15) & ~15), ldb = uni32(dsc->pad) ? small_ld(n) : ((n + 15) & ~15);
+    // dsc->pad = 1: leading dimensions == 17 mod 32 (fragment reads nearly conflict free); 0: tight (2-way read conflicts, fits more)
+    const int lda = uni32(dsc->pad) ? small_ld(m) : tight_ld(m), ldb = uni32(dsc->pad) ? small_ld(n) : tight_ld(n);
     lds_f64* As = (lds_f64*)lds;                       // As[kk*lda + row]
     lds_f64* Bs = As + k * lda;                        // Bs[kk*ldb + col]
     const bool a_kfast = minstride(A.c) < minstride(A.r);
     const bool b_kfast = minstride(B.r) < minstride(B.c);
-    // ---- stage all of A (m x k) and B (k x n), zero padding rows/cols up to the tile edge ----
     const int mp = (m + 15) & ~15, np = (n + 15) & ~15;
-    for (int e = tid; e < mp * k; e += TTN_WG) {
-        int r, kk;
-        if (a_kfast) { kk = e % k; r = e / k; } else { r = e % mp; kk = e / mp; }
-        As[kk * lda + r] = (r < m) ? A.p[ix(A.r, r) + ix(A.c, kk)] : 0.0;
+    // ---- offset tables (m, n <= 128; k <= 512 because k*(lda+ldb) <= GEMM_LDS_DOUBLES and lda, ldb >= 16) ----
+    gmem_f64* Ag = (gmem_f64*)A.p;
+    gmem_f64* Bg = (gmem_f64*)B.p;
+    lds_i64* rowA = (lds_i64*)(lds + GEMM_LDS_DOUBLES + 32);
+    lds_i64* colB = rowA + 128;
+    lds_i64* rowC = colB + 128;
+    lds_i64* colC = rowC + 128;
+    lds_i64* kA = colC + 128;
+    lds_i64* kB = kA + 512;
+    for (int i = tid; i < 128; i += TTN_WG) {
+        rowA[i] = (i < m) ? ix(A.r, i) : 0;
+        rowC[i] = (i < m) ? ix(C.r, i) : 0;
+        colB[i] = (i < n) ? ix(B.c, i) : 0;
+        colC[i] = (i < n) ? ix(C.c, i) : 0;
     }
-    for (int e = tid; e < np * k; e += TTN_WG) {
-        int c, kk;
-        if (b_kfast) { kk = e % k; c = e / k; } else { c = e % np; kk = e / np; }
-        Bs[kk * ldb + c] = (c < n) ? B.p[ix(B.r, kk) + ix(B.c, c)] : 0.0;
+    for (int i = tid; i < k; i += TTN_WG) { kA[i] = ix(A.c, i); kB[i] = ix(B.r, i); }
+    __syncthreads();
+    // ---- stage all of A (m x k) and B (k x n), zero padding rows/cols up to the tile edge; 16 lanes walk the
+    //      operand's fast (small-stride) index, the 64 lane groups its slow index: no divisions in the loops ----
+    const int fx = tid & 15, sy = tid >> 4;
+    if (a_kfast) {
+        for (int r = sy; r < mp; r += TTN_WG / 16) {
+            const long long ro = rowA[r];
+            for (int kk = fx; kk < k; kk += 16) As[kk * lda + r] = (r < m) ? Ag[ro + kA[kk]] : 0.0;
+        }
+    } else {
+        for (int kk = sy; kk < k; kk += TTN_WG / 16) {
+            const long long ko = kA[kk];
+            for (int r = fx; r < mp; r += 16) As[kk * lda + r] = (r < m) ? Ag[rowA[r] + ko] : 0.0;
+        }
+    }
+    if (b_kfast) {
+        for (int c = sy; c < np; c += TTN_WG / 16) {
+            const long long co = colB[c];
+            for (int kk = fx; kk < k; kk += 16) Bs[kk * ldb + c] = (c < n) ? Bg[co + kB[kk]] : 0.0;
+        }
+    } else {
+        for (int kk = sy; kk < k; kk += TTN_WG / 16) {
+            const long long ko = kB[kk];
+            for (int c = fx; c < np; c += 16) Bs[kk * ldb + c] = (c < n) ? Bg[colB[c] + ko] : 0.0;
+        }
     }
     __syncthreads();
     const int tm = mp >> 4, tn = np >> 4, ntile = tm * tn;
@@ -221,21 +334,27 @@ __device__ __noinline__ void wg_gemm_small_impl(const GemmDesc* dsc, double* lds
     for (int tile = wave; tile < ntile; tile += (TTN_WG >> 6)) {
         const int r0 = (tile % tm) << 4, c0 = (tile / tm) << 4;
         mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
-        for (int t = 0; t < k4; ++t) {
-            const int kr = 4 * t + lk;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[kr * lda + r0 + li], Bs[kr * ldb + c0 + li], acc, 0, 0, 0);
+        const lds_f64* ap = As + lk * lda + r0 + li;
+        const lds_f64* bp = Bs + lk * ldb + c0 + li;
+        int t = 0;
+        for (; t + 4 <= k4; t += 4) {                   // four k-steps per trip: the eight LDS reads go out before the MFMAs
+            double a_[4], b_[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a_[q] = ap[(4 * (t + q)) * lda]; b_[q] = bp[(4 * (t + q)) * ldb]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[q], b_[q], acc, 0, 0, 0);
         }
+        for (; t < k4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[(4 * t) * lda], bp[(4 * t) * ldb], acc, 0, 0, 0);
         if (krem) {                                     // k not a multiple of 4: pad the last step with zeros
-            const int kr = 4 * k4 + lk;
-            const double a = (lk < krem) ? As[kr * lda + r0 + li] : 0.0;
-            const double b = (lk < krem) ? Bs[kr * ldb + c0 + li] : 0.0;
+            const double a = (lk < krem) ? ap[(4 * k4) * lda] : 0.0;
+            const double b = (lk < krem) ? bp[(4 * k4) * ldb] : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int gi = r0 + lk + 4 * reg, gj = c0 + li;
             if (gi < m && gj < n) {
-                double* cp = C.p + ix(C.r, gi) + ix(C.c, gj);
+                double* cp = C.p + rowC[gi] + colC[gj];
                 double v = alpha * acc[reg];
                 if (beta != 0.0) v += beta * (*cp);
                 *cp = v;
@@ -255,7 +374,7 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
     }
     __syncthreads();
     const bool shape_ok = (m <= 128) && (n <= 128) && (((m + 15) >> 4) * ((n + 15) >> 4) <= 32);
-    const int wpad = small_ld(m) + small_ld(n), wtight = ((m + 15) & ~15) + ((n + 15) & ~15);
+    const int wpad = small_ld(m) + small_ld(n), wtight = tight_ld(m) + tight_ld(n);
     if (shape_ok && (long long)k * wpad <= GEMM_LDS_DOUBLES) {
         if (threadIdx.x == 0) dsc->pad = 1;
         __syncthreads();
@@ -265,7 +384,9 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
     } else if (shape_ok && k <= 8 * (GEMM_LDS_DOUBLES / wtight)) {
         // few output tiles but a long K: the tiled GEMM would keep most waves idle; run the one-shot kernel over
         // K chunks, accumulating into C (plain-stride k index assumed only through the Views: chunks shift A.c / B.r)
-        const int kc = (GEMM_LDS_DOUBLES / wtight) & ~3;
+        const int kcmax = (GEMM_LDS_DOUBLES / wtight) & ~3;
+        const int nck = (k + kcmax - 1) / kcmax;
+        const int kc = (((k + nck - 1) / nck) + 3) & ~3;                  // balanced chunks, multiples of 4
         for (int k0 = 0; k0 < k; k0 += kc) {
             if (k0 > 0) __syncthreads();
             if (threadIdx.x == 0) {
@@ -796,43 +917,124 @@ __device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* n
 // Cholesky G = L L^T in LDS (column-major, leading dimension 128, n <= 128), in place: on exit the lower
 // triangle holds L and the strict upper triangle is zeroed.  Returns 0, or 1 if a pivot is not safely
 // positive (d_j <= n*eps*max_diag): the caller then falls back to the Householder path.
+// Blocked right-looking, panel width 16, three workgroup barriers per PANEL (the unblocked form it replaces took one
+// per column and ~2.7 k clk per column of LDS read-modify-write traffic: 355 k clk for n = 128):
+//   (a) wave 0 factors the 16x16 diagonal block in LDS (wave-level ordering only) and leaves 1/l_kk in red[0..15];
+//   (b) one thread per row below the block solves its row of L21 = A21 L11^-T in registers;
+//   (c) the trailing matrix gets A22 -= L21 L21^T by fp64 MFMA, one 16x16 tile of the lower triangle per wave and trip,
+//       operands read straight from the LDS image.
 // -------------------------------------------------------------------------------------------------
 __device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
-    const int tid = threadIdx.x;
-    const int ti = tid & 127, tc = tid >> 7;             // row within a column, column group (TTN_WG/128 columns per pass)
-    constexpr int NCG = TTN_WG / 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    const int li = lane & 15, lk = lane >> 4;
     lds_f64* G = (lds_f64*)Gg;
+    lds_f64* invd = (lds_f64*)red;                       // 1 / l_kk of the current panel (red[0..15], free between reductions)
     double dmax = 0.0;
     for (int j = tid; j < n; j += TTN_WG) dmax = fmax(dmax, G[j * 128 + j]);
     dmax = wg_max(dmax, red);
     const double dmin = (double)n * DBL_EPSILON * dmax;
     if (tid == 0) *flag = 0;
     __syncthreads();
-    // Right-looking, ONE barrier per step: column j stays UNSCALED while it is used
-    // (G[i][c] -= G[i][j] * G[c][j] / d_j) and all columns are scaled by 1/sqrt(d_j) in a final pass.
-    double pmin = dmax;
+    double pmin = dmax;                                  // tracked by wave 0 (every lane sees every pivot)
     int bad = 0;
-    for (int j = 0; j < n; ++j) {
-        const double d = G[j * 128 + j];                 // final value of the pivot: every thread reads the same d
-        if (!(d > dmin)) { bad = 1; break; }
-        pmin = fmin(pmin, d);
-        const double dinv = 1.0 / d;
-        if (ti > j && ti < n) {
-            const double lij = G[j * 128 + ti] * dinv;   // G[i][j] / d_j
-            for (int c = j + 1 + tc; c <= ti; c += NCG)
-                G[c * 128 + ti] = fma(-lij, G[j * 128 + c], G[c * 128 + ti]);
+#ifdef CHOL_PROF
+    long long cp_[4] = {0, 0, 0, 0};
+#define CPM(k) { const long long t_ = __builtin_amdgcn_s_memtime(); cp_[k] += t_ - cpt_; cpt_ = t_; }
+#else
+#define CPM(k)
+#endif
+    for (int j0 = 0; j0 < n; j0 += 16) {
+        const int jb = (n - j0 < 16) ? n - j0 : 16;
+#ifdef CHOL_PROF
+        long long cpt_ = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- (a) diagonal block, wave 0, in REGISTERS: lane (li, lk) holds D[li][lk + 4q], q = 0..3.  Per column one LDS
+        //      round trip: the owners publish the unscaled column, every lane reads the pivot, its row's and its columns'
+        //      entries and applies the rank-1 update to its four elements ----
+        if (wave == 0) {
+            lds_f64* D = G + j0 * 128 + j0;              // D[c*128 + i]
+            lds_f64* colbuf = invd + 16;                 // red[16..31]
+            double e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int c = lk + 4 * q; e[q] = (li < jb && c <= li) ? D[c * 128 + li] : 0.0; }
+            // A lone wave issues one fp64 instruction per ~9 clk, so the step is written with as few as possible: no
+            // per-element predicates.  Entries above the diagonal are PUBLISHED as zero, which makes the update of an
+            // already final column (c < jj) vanish by itself; the unpublished upper entries a lane holds just carry
+            // bounded garbage that is never read or written back.
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                if (jj >= jb) break;
+                if (lk == (jj & 3)) colbuf[li] = (li >= jj) ? e[jj >> 2] : 0.0;
+                __builtin_amdgcn_wave_barrier();
+                const double d = colbuf[jj], ali = colbuf[li];
+                double ac[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ac[q] = colbuf[lk + 4 * q];
+                if (!(d > dmin)) { if (lane == 0) *flag = 1; break; }
+                pmin = fmin(pmin, d);
+                const double rs = fast_rsqrt2(d);
+                const double lli = ali * rs, nl = -lli * rs;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = fma(nl, ac[q], e[q]);
+                // column jj is final: l_ij = a_ij / sqrt(d) below the diagonal, sqrt(d) = d * rs on it (the update above left 0 there)
+                if (lk == (jj & 3) && li >= jj) e[jj >> 2] = lli;
+                if (lane == 0) invd[jj] = rs;
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int c = lk + 4 * q; if (li < jb && c <= li) D[c * 128 + li] = e[q]; }
         }
         __syncthreads();
-    }
-    if (!bad) {
-        for (int c = tc; c < n; c += NCG) {
-            const double inv = 1.0 / sqrt(G[c * 128 + c]);
-            __builtin_amdgcn_wave_barrier();
-            if (ti > c && ti < n) G[c * 128 + ti] *= inv;
+        CPM(0)
+        if (*flag) { bad = 1; break; }
+        const int s0 = j0 + jb, sr = n - s0;             // first row / number of rows below the block
+        if (sr > 0) {                                    // then jb == 16
+            // ---- (b) rows below the block: x L11^T = a, right-looking in registers ----
+            if (tid < sr) {
+                const int r = s0 + tid;
+                double a[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] = G[(j0 + c) * 128 + r];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    a[k] *= invd[k];
+#pragma unroll
+                    for (int c = k + 1; c < 16; ++c) a[c] = fma(-a[k], G[(j0 + k) * 128 + j0 + c], a[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) G[(j0 + c) * 128 + r] = a[c];
+            }
+            __syncthreads();
+            CPM(1)
+            // ---- (c) trailing update, lower-triangle tiles (tr >= tc) ----
+            const int nt = (sr + 15) >> 4, ntiles = nt * (nt + 1) / 2;
+            for (int tile = wave; tile < ntiles; tile += nwaves) {
+                int tr = 0, base = 0;
+                while (base + tr + 1 <= tile) { base += tr + 1; ++tr; }      // tile = tr(tr+1)/2 + tc
+                const int tc = tile - base;
+                const int r0 = s0 + 16 * tr, c0 = s0 + 16 * tc;
+                mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const lds_f64* col = G + (j0 + 4 * t + lk) * 128;
+                    const double av = (r0 + li < n) ? col[r0 + li] : 0.0;
+                    const double bv = (c0 + li < n) ? col[c0 + li] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = r0 + lk + 4 * reg, colj = c0 + li;
+                    if (row < n && colj < n && row >= colj) G[colj * 128 + row] -= acc[reg];
+                }
+            }
+            __syncthreads();
+            CPM(2)
         }
-        __syncthreads();
-        for (int c = tid; c < n; c += TTN_WG) G[c * 128 + c] = sqrt(G[c * 128 + c]);
     }
+#ifdef CHOL_PROF
+    if (tid == 0) { pivmin_out[2] += (double)cp_[0]; pivmin_out[3] += (double)cp_[1]; pivmin_out[4] += (double)cp_[2]; }
+#endif
+#undef CPM
     // pivots lie between the extreme eigenvalues of G, so dmax/pmin is a LOWER bound of cond(G) = cond(M)^2
     if (tid == 0) *pivmin_out = (!bad && pmin > 0.0) ? dmax / pmin : 1.0e300;
     for (int e = tid; e < n * 128; e += TTN_WG) { const int c = e >> 7, i = e & 127; if (i < c) G[c * 128 + i] = 0.0; }
@@ -1020,17 +1222,17 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             wg_gemm(rm, rm, q, Bp, tview(Bp), Gbv, 1.0 / (sB * sB), 0.0, lds);          // B' B'^T
             PROF_MARK(8)
             // L_A
-            for (int e = tid; e < rm * rm; e += TTN_WG) S.ldsX[(e / rm) * 128 + e % rm] = S.Ga[(e / rm) * 128 + e % rm];
+            for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.ldsX[e] = S.Ga[e];
             __syncthreads();
             ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
-            for (int e = tid; e < rm * rm; e += TTN_WG) S.Ga[(e / rm) * 128 + e % rm] = S.ldsX[(e / rm) * 128 + e % rm];
+            for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.Ga[e] = S.ldsX[e];
             __syncthreads();
         }
         if (ok) {
-            for (int e = tid; e < rm * rm; e += TTN_WG) S.ldsX[(e / rm) * 128 + e % rm] = S.Gb[(e / rm) * 128 + e % rm];
+            for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.ldsX[e] = S.Gb[e];
             __syncthreads();
             ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
-            for (int e = tid; e < rm * rm; e += TTN_WG) S.Gb[(e / rm) * 128 + e % rm] = S.ldsX[(e / rm) * 128 + e % rm];
+            for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.Gb[e] = S.ldsX[e];
             __syncthreads();
         }
         int r = 0, rk = 0;
@@ -1128,7 +1330,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
                 // =========================== route G: L = chol(M M^T) ===========================
                 wg_gemm(p, p, q, Mv, tview(Mv), mkview(S.Ga, plain(1), plain(128)), 1.0, 0.0, lds);
                 PROF_MARK(7)
-                for (int e = tid; e < p * p; e += TTN_WG) S.ldsX[(e / p) * 128 + e % p] = S.Ga[(e / p) * 128 + e % p];
+                for (int e = tid; e < p * 128; e += TTN_WG) if ((e & 127) < p) S.ldsX[e] = S.Ga[e];
                 __syncthreads();
                 ok = wg_chol_lds128(p, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
                 // with truncerr > 0 the rank rule reads the SMALL singular values too: need cond(M) <= kappa_max overall
@@ -1306,4 +1508,34 @@ __global__ void __launch_bounds__(TTN_WG) k_bench_gemm(int m, int n, int k, doub
     __syncthreads();
     const long long t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) *cycles = t1 - t0;
+}
+
+// LDS building-block micro-benchmark (ttn_bench_lds): G = I*n + smooth symmetric perturbation, then Cholesky or Jacobi.
+__global__ void __launch_bounds__(TTN_WG) k_bench_lds(int what, int n, int reps, long long* out) {
+    extern __shared__ double lds[];
+    double* red = lds + GEMM_LDS_TOTAL;
+    double* scal = red + 32;
+    int* iflag = (int*)(scal + 8);
+    double* nrm2 = scal + 16;
+    int sw = 0;
+    if (threadIdx.x < 8) scal[threadIdx.x] = 0.0;
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < reps; ++r) {
+        for (int e = threadIdx.x; e < 128 * 128; e += TTN_WG) {
+            const int c = e >> 7, i = e & 127;
+            lds[e] = (i < n && c < n) ? ((i == c) ? (double)n : 1.0 / (1.0 + (i > c ? i - c : c - i))) : 0.0;
+        }
+        __syncthreads();
+        if (what == 1) wg_chol_lds128(n, lds, red, iflag, scal + 1);
+        if (what == 2) sw = wg_jacobi_lds128(n, n, lds, nrm2, iflag, red, 1.0, 1.0, scal);
+        __syncthreads();
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = t1 - t0; out[1] = sw;
+#ifdef CHOL_PROF
+        printf("chol phases (a) %.0f (b) %.0f (c) %.0f clk per call\n", scal[3] / reps, scal[4] / reps, scal[5] / reps);
+#endif
+    }
 }

@@ -17,3 +17,12 @@ for m, n, k, ta, tb, what in shapes:
     per = cy.value / reps
     flop = 2.0 * m * n * k
     print(f"{what:20s} {m:4d}x{n:4d}x{k:4d} ta={ta} tb={tb}: {per:10.0f} clk  {flop/per:6.1f} flop/clk  ({100*flop/per/128:5.1f}% of CU peak)")
+
+for n in (64, 128):
+    reps = 10
+    c0, c1, c2, sw = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    T._lib.check(L.ttn_bench_lds(0, n, reps, C.byref(c0), None))
+    T._lib.check(L.ttn_bench_lds(1, n, reps, C.byref(c1), None))
+    T._lib.check(L.ttn_bench_lds(2, n, reps, C.byref(c2), C.byref(sw)))
+    print(f"LDS n={n}: setup {c0.value/reps:.0f} clk, Cholesky {(c1.value-c0.value)/reps:.0f} clk, "
+          f"Jacobi {(c2.value-c0.value)/reps:.0f} clk in {sw.value} sweeps = {(c2.value-c0.value)/reps/max(sw.value,1):.0f} clk/sweep")
