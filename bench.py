@@ -92,6 +92,65 @@ def cpu_baseline(d, rank, budget_s=20.0):
     return out
 
 
+def bench_core_sharded(args, T, D, torch, dist, rank, world, red_device):
+    """--shard cores: every chain is cut core-wise into `world` segments (pipeline.py), micro-batches of --batch trains are
+    pipelined through the ranks with one boundary-core hand-off per segment boundary, direction and micro-batch.  One STEP
+    = tt_compress!(Delta*x, r) of ALL micro-batches; value = microbatches * batch * d / max-over-ranks step time (strong
+    scaling of a fixed set of chains: the work per GPU shrinks with N).  No roofline/cpu legs: the kernels are the same."""
+    import numpy as np
+    from ttn_amd import pipeline as PL
+    d, r, B = args.d, args.rank, args.batch
+    M = args.microbatches if args.microbatches > 0 else 2 * world
+    A = T.Delta(d)
+    lo, hi = PL.extended_range(d, rank, world)
+    backend = PL.DeviceBackend()
+    comm_dev = "cuda" if args.backend == "nccl" else "cpu"
+    transport = PL.DistTransport(dist, comm_dev) if dist is not None else None
+    A_cores = [np.asfortranarray(c) for c in A.tto_vec[lo:hi]]
+    prepared = []
+    for m in range(M):
+        trains = [[np.asfortranarray(c) for c in T.rand_tt((2,) * d, r, seed=30 + m * B + b).ttv_vec[lo:hi]] for b in range(B)]
+        prepared.append(backend.prepare(A_cores, A.tto_rks[lo:hi + 1], trains, (2,) * (hi - lo)))
+
+    def barrier():
+        D.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        return PL.sharded_apply_compress(backend, transport, rank, world, prepared, hi - lo, r)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        segs = step()
+    D.sync()
+    torch.cuda.synchronize()
+    elapsed = T.shard.max_over_ranks(time.perf_counter() - t0, dist, device=red_device)
+    if dist is not None:
+        dist.barrier()
+    rks_local = segs[0].ranks(0)[0]
+    if rank == 0:
+        res = {
+            "metric": "TT cores/sec for QTT Laplacian apply+round, d=%d rank-%d" % (d, r),
+            "value": round(M * B * d / (elapsed / args.steps), 1), "unit": "TT cores/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4: tt_compress!(Delta(%d)*x, %d), every chain cut core-wise into %d segments, %d micro-batches "
+                                   "of %d trains pipelined through the ranks, boundary-core hand-offs over %s" %
+                                   (d, r, world, M, B, "RCCL (xGMI)" if args.backend == "nccl" else args.backend),
+                       "d": d, "rank": r, "batch_per_microbatch": B, "microbatches": M,
+                       "parallelism": "core-wise pipeline over %d GPU(s)" % world, "rank0_segment_out_ranks": rks_local},
+        }
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +161,10 @@ def main():
     ap.add_argument("--rank", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
+    ap.add_argument("--shard", default="trains", choices=["trains", "cores"],
+                    help="N>1: 'trains' (default) = independent trains per GPU, no data-path collective; 'cores' = every chain cut "
+                         "core-wise into N segments with boundary-core hand-offs (pipeline.py; micro-batches of --batch trains)")
+    ap.add_argument("--microbatches", type=int, default=0, help="--shard cores: micro-batches in flight per step (default 2*N)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                                                         "the multi-process path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -131,6 +194,8 @@ def main():
     T.ensure_init(dev_index)
 
     d, r, B = args.d, args.rank, args.batch
+    if args.shard == "cores":
+        return bench_core_sharded(args, T, D, torch, dist, rank, world, red_device)
     A = T.Delta(d)
     dA = T.DeviceTTO(A)
     x0 = T.rand_tt((2,) * d, r, seed=30)

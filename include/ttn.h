@@ -103,6 +103,18 @@ int ttn_compress_rank_bound(int64_t d, const int64_t* dims, const int64_t* rks, 
 /* _tt_bond_truncate!(psi, k; max_bond, truncerr) without the discarded orthogonalize; k is 1-based */
 int ttn_bond_truncate(ttn_tt_t psi, int64_t k, int64_t max_bond, double truncerr);
 
+/* --- core-wise sharded chains (one segment of the chain per GPU, boundary-core hand-offs between neighbours).
+ * A segment is an ordinary handle whose boundary ranks need not be 1.
+ * ttn_sweep: the bond steps of src/tt_tools.jl:780-785 restricted to one direction over the bonds k_first .. k_last
+ * (1-based like ttn_bond_truncate; descending when k_first > k_last).
+ * ttn_tt_core_extent / _export / _import: move core k (1-based) of every train to / from a dense device buffer
+ * [batch][dims[k]*bound_left*bound_right] plus its two ranks [batch][2] (device pointers, e.g. of the tensor handed to
+ * ncclSend/ncclRecv); import sets the host-side rank bounds the sender reports. */
+int ttn_sweep(ttn_tt_t psi, int64_t k_first, int64_t k_last, int64_t max_bond, double truncerr);
+int ttn_tt_core_extent(ttn_tt_t h, int64_t k, int64_t* doubles_per_train, int64_t* bound_left, int64_t* bound_right);
+int ttn_tt_core_export(ttn_tt_t h, int64_t k, double* dev_buf, int64_t* dev_rks2);
+int ttn_tt_core_import(ttn_tt_t h, int64_t k, const double* dev_buf, const int64_t* dev_rks2, int64_t bound_left, int64_t bound_right);
+
 /* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);
 

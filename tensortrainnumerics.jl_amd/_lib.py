@@ -58,6 +58,10 @@ SIGNATURES = {
     "ttn_compress_rank_bound": (C.c_int, [i64, p_i64, p_i64, i64, i64, i64, p_i64, p_i64]),
     "ttn_bond_truncate": (C.c_int, [handle, i64, i64, C.c_double]),
     "ttn_apply_compress": (C.c_int, [handle, handle, handle, i64, C.c_double, i64]),
+    "ttn_sweep": (C.c_int, [handle, i64, i64, i64, C.c_double]),
+    "ttn_tt_core_extent": (C.c_int, [handle, i64, p_i64, p_i64, p_i64]),
+    "ttn_tt_core_export": (C.c_int, [handle, i64, C.c_void_p, C.c_void_p]),
+    "ttn_tt_core_import": (C.c_int, [handle, i64, C.c_void_p, C.c_void_p, i64, i64]),
     "ttn_dot": (C.c_int, [handle, handle, p_f64]),
     "ttn_norm": (C.c_int, [handle, p_f64]),
     "ttn_hadamard": (C.c_int, [handle, handle, handle]),

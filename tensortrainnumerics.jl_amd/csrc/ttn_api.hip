@@ -585,7 +585,8 @@ int ttn_scale_batch(const double* a, ttn_tt_t x, ttn_tt_t y) {
 // so a bond rank can GROW when it was below both of those (rank-deficient input).  need[m] = largest rank bond m can
 // take at any time (buffers / handle capacity must hold it), fin[m] = bound after the call.
 static void rank_bounds(int d, const int64_t* dims, const int64_t* rks, int64_t max_bond, int64_t sweeps, int64_t k_single,
-                        std::vector<int64_t>& need, std::vector<int64_t>& fin, long long& pmax, long long& qmax) {
+                        std::vector<int64_t>& need, std::vector<int64_t>& fin, long long& pmax, long long& qmax,
+                        int64_t k_first = 0, int64_t k_last = 0 /* 0-based bond range when k_single < 0 */) {
     fin.assign(rks, rks + d + 1);
     need = fin;
     pmax = 1; qmax = 1;
@@ -597,6 +598,11 @@ static void rank_bounds(int d, const int64_t* dims, const int64_t* rks, int64_t 
         need[k + 1] = std::max(need[k + 1], fin[k + 1]);
     };
     if (k_single > 0) { stepk((int)k_single - 1); return; }
+    if (k_single < 0) {
+        if (k_first <= k_last) { for (int64_t k = k_first; k <= k_last; ++k) stepk((int)k); }
+        else { for (int64_t k = k_first; k >= k_last; --k) stepk((int)k); }
+        return;
+    }
     for (int64_t sw = 0; sw < sweeps; ++sw) {
         for (int k = 0; k + 1 < d; ++k) stepk(k);
         for (int k = d - 2; k >= 0; --k) stepk(k);
@@ -614,12 +620,13 @@ int ttn_compress_rank_bound(int64_t d, const int64_t* dims, const int64_t* rks, 
     return TTN_OK;
 }
 
-static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, double truncerr, int64_t sweeps) {
+static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, double truncerr, int64_t sweeps,
+                           int64_t k_first = 0, int64_t k_last = 0) {
     const int d = psi->d;
     if (d < 2 && k_single == 0) return TTN_OK;
     std::vector<int64_t> need, fin;
     long long pmax = 1, qmax = 1;
-    rank_bounds(d, psi->dims.data(), psi->bound.data(), max_bond, sweeps, k_single, need, fin, pmax, qmax);
+    rank_bounds(d, psi->dims.data(), psi->bound.data(), max_bond, sweeps, k_single, need, fin, pmax, qmax, k_first, k_last);
     for (int m = 0; m <= d; ++m)
         if (need[m] > psi->cap[m]) return fail(TTN_ERR_CAPACITY, "ttn_compress: a bond rank can grow beyond the handle's capacity (see ttn_compress_rank_bound)");
     if (pmax > 4096 || qmax > 16384) return fail(TTN_ERR_UNSUPPORTED, "ttn_compress: merged matrix larger than 4096 x 16384");
@@ -628,7 +635,7 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     if (rc) return rc;
     rc = ensure_batch_bufs(psi->batch);
     if (rc) return rc;
-    const int steps = k_single ? 1 : (int)(2 * (d - 1) * sweeps);
+    const int steps = k_single > 0 ? 1 : (k_single < 0 ? (int)(std::llabs(k_last - k_first) + 1) : (int)(2 * (d - 1) * sweeps));
     if (psi->sv_on) {
         if (psi->sv_steps < steps || psi->sv_pmax < pmax) {
             if (psi->d_sv) { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipFree(psi->d_sv)); psi->d_sv = nullptr; }
@@ -643,6 +650,7 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     P.truncerr = truncerr;
     P.sweeps = (int)sweeps;
     P.k_single = (int)k_single;
+    P.k_first = (int)k_first; P.k_last = (int)k_last;
     P.scratch = (double*)g_scratch;
     P.scratch_stride = per_train;
     P.pmax = (int)pmax; P.qmax = (int)qmax;
@@ -683,6 +691,55 @@ int ttn_bond_truncate(ttn_tt_t psi, int64_t k, int64_t max_bond, double truncerr
     if (k < 1 || k >= psi->d) return fail(TTN_ERR_BOND_INDEX, "k must be in 1:(N-1)");
     if (max_bond < 1) return fail(TTN_ERR_ARG, "max_bond must be >= 1");
     return launch_compress(psi, k, max_bond, truncerr, 1);
+}
+
+int ttn_sweep(ttn_tt_t psi, int64_t k_first, int64_t k_last, int64_t max_bond, double truncerr) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!psi) return fail(TTN_ERR_ARG, "null handle");
+    if (k_first < 1 || k_first >= psi->d || k_last < 1 || k_last >= psi->d) return fail(TTN_ERR_BOND_INDEX, "k must be in 1:(N-1)");
+    if (max_bond < 1) return fail(TTN_ERR_ARG, "max_bond must be >= 1");
+    return launch_compress(psi, -1, max_bond, truncerr, 1, k_first - 1, k_last - 1);
+}
+
+// ---- boundary-core hand-off of core-wise sharded chains --------------------------------------------
+// A core is stored compactly (current ranks) at the start of its slot, so the first dims[k]*bound[k]*bound[k+1] doubles
+// of every train's slot carry it; they move to / from a dense [batch][that many] device buffer with one 2-D copy.
+int ttn_tt_core_extent(ttn_tt_t h, int64_t k, int64_t* doubles_per_train, int64_t* bound_left, int64_t* bound_right) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!h || k < 1 || k > h->d) return fail(TTN_ERR_ARG, "bad core index");
+    const int64_t bl = h->bound[k - 1], br = h->bound[k];
+    if (doubles_per_train) *doubles_per_train = h->dims[k - 1] * bl * br;
+    if (bound_left) *bound_left = bl;
+    if (bound_right) *bound_right = br;
+    return TTN_OK;
+}
+
+int ttn_tt_core_export(ttn_tt_t h, int64_t k, double* dev_buf, int64_t* dev_rks2) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!h || !dev_buf || !dev_rks2 || k < 1 || k > h->d) return fail(TTN_ERR_ARG, "bad argument");
+    const size_t w = sizeof(double) * (size_t)(h->dims[k - 1] * h->bound[k - 1] * h->bound[k]);
+    HIPCHK(hipMemcpy2DAsync(dev_buf, w, h->d_data + h->off[k - 1], sizeof(double) * (size_t)h->stride, w, h->batch,
+                            hipMemcpyDeviceToDevice, g_stream));
+    HIPCHK(hipMemcpy2DAsync(dev_rks2, 2 * sizeof(long long), h->d_rks + (k - 1), sizeof(long long) * (size_t)(h->d + 1),
+                            2 * sizeof(long long), h->batch, hipMemcpyDeviceToDevice, g_stream));
+    return TTN_OK;
+}
+
+int ttn_tt_core_import(ttn_tt_t h, int64_t k, const double* dev_buf, const int64_t* dev_rks2, int64_t bound_left, int64_t bound_right) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!h || !dev_buf || !dev_rks2 || k < 1 || k > h->d || bound_left < 1 || bound_right < 1) return fail(TTN_ERR_ARG, "bad argument");
+    if (bound_left > h->cap[k - 1] || bound_right > h->cap[k]) return fail(TTN_ERR_CAPACITY, "ttn_tt_core_import: core does not fit the slot");
+    const size_t w = sizeof(double) * (size_t)(h->dims[k - 1] * bound_left * bound_right);
+    HIPCHK(hipMemcpy2DAsync(h->d_data + h->off[k - 1], sizeof(double) * (size_t)h->stride, dev_buf, w, w, h->batch,
+                            hipMemcpyDeviceToDevice, g_stream));
+    HIPCHK(hipMemcpy2DAsync(h->d_rks + (k - 1), sizeof(long long) * (size_t)(h->d + 1), dev_rks2, 2 * sizeof(long long),
+                            2 * sizeof(long long), h->batch, hipMemcpyDeviceToDevice, g_stream));
+    h->bound[k - 1] = bound_left;
+    h->bound[k] = bound_right;
+    return TTN_OK;
 }
 
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps) {

@@ -23,6 +23,19 @@
 #define GEMM_TILE_DOUBLES (2 * GEMM_BK * GEMM_LD)   // one LDS stage (A and B chunk) of the tiled (big) GEMM; it keeps two
 #define GEMM_LDS_DOUBLES (128 * 128 + 512)         // LDS region every GEMM may use (the one-shot small GEMM uses all of it): the 128x128
                                                    // Jacobi image + room for the odd leading dimensions of a 64x64x128 one-shot product
+// Call-boundary policy of the big building blocks (experiments: -DTTN_NI_JACOBI=inline etc.)
+#ifndef TTN_NI_JACOBI
+#define TTN_NI_JACOBI __noinline__
+#endif
+#ifndef TTN_NI_CHOL
+#define TTN_NI_CHOL __noinline__
+#endif
+#ifndef TTN_NI_GEMM
+#define TTN_NI_GEMM __noinline__
+#endif
+#ifndef TTN_NI_GEMMS
+#define TTN_NI_GEMMS __noinline__
+#endif
 #define QR_NB 16                         // Householder panel width
 #define JACOBI_MAX_SWEEPS 40
 
@@ -78,8 +91,9 @@ struct GemmDesc {
     int m, n, k, pad;
     View A, B, C;
     double alpha, beta;
+    unsigned long long* amax;   // null, or an LDS word that receives max |C_ij| over the stored values (bits of a non-negative double)
 };
-// Behind the LDS tiles: the descriptor (sizeof(GemmDesc) = 200 bytes, 32 doubles reserved) and the OFFSET TABLES.
+// Behind the LDS tiles: the descriptor (sizeof(GemmDesc) = 208 bytes, 32 doubles reserved) and the OFFSET TABLES.
 // Operands are 2-level strided Views, so an element address costs two integer divisions; a GEMM evaluates ix() once per
 // row / column / k index into these tables and the staging loops only add table entries.
 #define GEMM_TAB_ENTRIES 1536
@@ -106,7 +120,17 @@ __device__ inline double unif64(double v) { union { double d; long long i; } u; 
 __device__ inline Idx uniIdx(const Idx& d) { return Idx{uni32(d.q), uni64(d.lo), uni64(d.hi)}; }
 __device__ inline View uniView(const View& v) { return View{(double*)uni64((long long)v.p), uniIdx(v.r), uniIdx(v.c)}; }
 
-__device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
+// max |C_ij| of the values a GEMM stored, for callers that rescale by it: saves a pass over C (wave max, then one LDS
+// atomic per wave; non-negative doubles order like their bit patterns)
+__device__ inline void gemm_publish_amax(const GemmDesc* dsc, double cmax) {
+    unsigned long long* am = (unsigned long long*)uni64((long long)dsc->amax);
+    if (am) {
+        cmax = wave_max(cmax);
+        if ((threadIdx.x & 63) == 0) atomicMax(am, (unsigned long long)__double_as_longlong(cmax));
+    }
+}
+
+__device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
     const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
     const View A = uniView(dsc->A), B = uniView(dsc->B), C = uniView(dsc->C);
     const double alpha = unif64(dsc->alpha), beta = unif64(dsc->beta);
@@ -132,6 +156,7 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
         const int e = tid + TTN_WG * u;
         if (b_kfast) { bkk[u] = e & (GEMM_BK - 1); bc[u] = e / GEMM_BK; } else { bc[u] = e & (GEMM_BN - 1); bkk[u] = e / GEMM_BN; }
     }
+    double cmax = 0.0;
     const int nch = (k + GEMM_BK - 1) / GEMM_BK;
     int slab0 = -1;                                               // first k index the tables currently hold
     for (int m0 = 0; m0 < m; m0 += GEMM_BM) {
@@ -256,11 +281,13 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
                             double v = alpha * acc[ti][tj][reg];
                             if (beta != 0.0) v += beta * (*cp);
                             *cp = v;
+                            cmax = fmax(cmax, fabs(v));
                         }
                     }
             }
         }
     }
+    gemm_publish_amax(dsc, cmax);
     __syncthreads();
 }
 
@@ -273,7 +300,7 @@ __device__ __noinline__ void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
 __device__ inline int small_ld(int x) { const int t = (x + 15) & ~15; return (((t & 31) == 16) ? t : t + 16) + 1; }   // == 17 mod 32 (see GEMM_LD)
 __device__ inline int tight_ld(int x) { return ((x + 15) & ~15) + 1; }                                             // odd: conflict-free k-fast stores
 
-__device__ __noinline__ void wg_gemm_small_impl(const GemmDesc* dsc, double* lds) {
+__device__ TTN_NI_GEMMS void wg_gemm_small_impl(const GemmDesc* dsc, double* lds) {
     const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
     const View A = uniView(dsc->A), B = uniView(dsc->B), C = uniView(dsc->C);
     const double alpha = unif64(dsc->alpha), beta = unif64(dsc->beta);
@@ -331,6 +358,7 @@ __device__ __noinline__ void wg_gemm_small_impl(const GemmDesc* dsc, double* lds
     __syncthreads();
     const int tm = mp >> 4, tn = np >> 4, ntile = tm * tn;
     const int k4 = k >> 2, krem = k & 3;
+    double cmax = 0.0;
     for (int tile = wave; tile < ntile; tile += (TTN_WG >> 6)) {
         const int r0 = (tile % tm) << 4, c0 = (tile / tm) << 4;
         mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
@@ -358,19 +386,24 @@ __device__ __noinline__ void wg_gemm_small_impl(const GemmDesc* dsc, double* lds
                 double v = alpha * acc[reg];
                 if (beta != 0.0) v += beta * (*cp);
                 *cp = v;
+                cmax = fmax(cmax, fabs(v));
             }
         }
     }
+    gemm_publish_amax(dsc, cmax);
     __syncthreads();
 }
 
-__device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, double alpha, double beta, double* lds) {
+__device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, double alpha, double beta, double* lds,
+                               double* amax_lds = nullptr /* LDS word: receives max |C_ij| */) {
     GemmDesc* dsc = reinterpret_cast<GemmDesc*>(lds + GEMM_LDS_DOUBLES);
     __syncthreads();                         // nobody still reads what the tiles / descriptor alias
     if (threadIdx.x == 0) {
         dsc->m = m; dsc->n = n; dsc->k = k; dsc->pad = 0;
         dsc->A = A; dsc->B = B; dsc->C = C;
         dsc->alpha = alpha; dsc->beta = beta;
+        dsc->amax = (unsigned long long*)amax_lds;
+        if (amax_lds) *amax_lds = 0.0;
     }
     __syncthreads();
     const bool shape_ok = (m <= 128) && (n <= 128) && (((m + 15) >> 4) * ((n + 15) >> 4) <= 32);
@@ -394,6 +427,7 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
                 dsc->A.p = A.p + ix(A.c, k0);
                 dsc->B.p = B.p + ix(B.r, k0);
                 dsc->beta = (k0 == 0) ? beta : 1.0;
+                dsc->amax = (k0 + kc >= k) ? (unsigned long long*)amax_lds : nullptr;     // the last chunk stores the final values
             }
             __syncthreads();
             wg_gemm_small_impl(dsc, lds);
@@ -903,7 +937,7 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
 
 // Fast path of the one-sided Jacobi: p <= 128 columns of length m <= 128 in LDS, leading dimension 128; rows
 // [m, 128) of every column must be ZERO (the caller pads).  See jacobi_lds128_body.
-__device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* nrm2g, int* flag, double* red,
+__device__ TTN_NI_JACOBI int wg_jacobi_lds128(int m, int p, double* Xg, double* nrm2g, int* flag, double* red,
                                              double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
     if (p < 2) { if (threadIdx.x == 0) *aneg_out = 0.0; __syncthreads(); return 0; }
     lds_f64* X = (lds_f64*)Xg;
@@ -924,7 +958,7 @@ __device__ __noinline__ int wg_jacobi_lds128(int m, int p, double* Xg, double* n
 //   (c) the trailing matrix gets A22 -= L21 L21^T by fp64 MFMA, one 16x16 tile of the lower triangle per wave and trip,
 //       operands read straight from the LDS image.
 // -------------------------------------------------------------------------------------------------
-__device__ __noinline__ int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
+__device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
     const int li = lane & 15, lk = lane >> 4;
     lds_f64* G = (lds_f64*)Gg;
@@ -1050,7 +1084,8 @@ struct CompressArgs {
     long long max_bond;
     double truncerr;
     int sweeps;
-    int k_single;          // 0: full tt_compress! sweeps; else 1-based bond for _tt_bond_truncate!
+    int k_single;          // 0: full tt_compress! sweeps; > 0: 1-based bond for _tt_bond_truncate!; < 0: the bond range below
+    int k_first, k_last;   // k_single < 0: 0-based bonds k_first .. k_last in that order (descending if k_first > k_last)
     double* scratch;       // per-train global scratch
     long long scratch_stride;
     int pmax, qmax;        // bounds on the short / long side of any merged matrix
@@ -1309,15 +1344,13 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
     if (!done) {
         // ---- merge: M = A' * B'  (p x q), scaled to max|M| = 1 ----
         const View Mv = mkview(S.M, plain(q), plain(1));
-        wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds);
+        // M stays UNSCALED in memory: max|M| comes out of the GEMM epilogue and the consumers (Gram, LQ copy, output GEMM)
+        // apply 1/s0 as their alpha — no extra read-modify-write pass over the p x q matrix.
+        wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds, S.scal + 6);
         PROF_MARK(0)
-        double mx = 0.0;
-        for (long long e = tid; e < (long long)p * q; e += TTN_WG) mx = fmax(mx, fabs(S.M[e]));
-        mx = wg_max(mx, S.red);
+        const double mx = S.scal[6];
         const double s0 = (mx > 0.0) ? mx : 1.0;
         const double inv_s0 = 1.0 / s0;
-        for (long long e = tid; e < (long long)p * q; e += TTN_WG) S.M[e] *= inv_s0;
-        __syncthreads();
         PROF_MARK(1)
         const bool need_lq = q > p;
         const bool x_in_lds = p <= 128;                       // fast Jacobi: X in LDS with leading dimension 128
@@ -1328,7 +1361,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             bool ok = true;
             if (attempt == 1) {
                 // =========================== route G: L = chol(M M^T) ===========================
-                wg_gemm(p, p, q, Mv, tview(Mv), mkview(S.Ga, plain(1), plain(128)), 1.0, 0.0, lds);
+                wg_gemm(p, p, q, Mv, tview(Mv), mkview(S.Ga, plain(1), plain(128)), inv_s0 * inv_s0, 0.0, lds);
                 PROF_MARK(7)
                 for (int e = tid; e < p * 128; e += TTN_WG) if ((e & 127) < p) S.ldsX[e] = S.Ga[e];
                 __syncthreads();
@@ -1341,14 +1374,14 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             } else {
                 // =========================== route H: Householder LQ ===========================
                 if (need_lq) {
-                    for (long long e = tid; e < (long long)p * q; e += TTN_WG) S.M2[e] = S.M[e];
+                    for (long long e = tid; e < (long long)p * q; e += TTN_WG) S.M2[e] = S.M[e] * inv_s0;
                     __syncthreads();
                     wg_lq_blocked(p, q, S.M2, q, S.Vb, S.Wb, nullptr, nullptr, lds, S.Ts, S.Ss, S.taus, S.red);
                 }
                 const double* Lsrc = need_lq ? S.M2 : S.M;               // row-major, ld = q
                 for (int e = tid; e < p * ldx; e += TTN_WG) {
                     const int r_ = e % ldx, c = e / ldx;              // X[r + ldx*c] = L[r][c]; rows >= p are zero padding
-                    const double v = (r_ < p) ? Lsrc[(long long)r_ * q + c] : 0.0;
+                    const double v = (r_ < p) ? Lsrc[(long long)r_ * q + c] * (need_lq ? 1.0 : inv_s0) : 0.0;
                     X[(long long)c * ldx + r_] = (need_lq && c > r_) ? 0.0 : v;
                 }
                 __syncthreads();
@@ -1376,7 +1409,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             }
             PROF_MARK(4)
             // ---- outputs.  left factor (p x r): x_j * sqrt(s0)/sqrt(sig_j) ; right factor (r x q):
-            //      (x_j^T M_scaled) * sqrt(s0) / (sig_j*sqrt(sig_j)).  Columns the Jacobi left alone as numerically
+            //      (x_j^T M / s0) * sqrt(s0) / (sig_j*sqrt(sig_j)).  Columns the Jacobi left alone as numerically
             //      zero (norm^2 <= aneg) are not singular vectors relative to their own size: written as exact zeros.
             const View Rfv = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * r});                 // (r x mc)
             const View Lo = wide ? Lfv : tview(Rfv);       // p x r
@@ -1394,7 +1427,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
                 S.Us[(long long)j * p + row] = us;            // Us^T stored: (r x p) row-major
             }
             __syncthreads();
-            wg_gemm(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, Ro, 1.0, 0.0, lds);
+            wg_gemm(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, Ro, inv_s0, 0.0, lds);
             if (attempt == 1) {
                 wg_gemm(r, r, q, Ro, tview(Ro), mkview(S.T2, plain(1), plain(128)), 1.0, 0.0, lds);
                 const double e2 = wg_check_diag(S, S.T2, 128, r, s0);
@@ -1429,6 +1462,11 @@ __global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {
     int step = 0;
     if (P.k_single > 0) {
         wg_bond_step(P, b, P.k_single - 1, step, lds);
+        return;
+    }
+    if (P.k_single < 0) {                                   // one direction of a sweep over a segment (ttn_sweep)
+        if (P.k_first <= P.k_last) { for (int k = P.k_first; k <= P.k_last; ++k) wg_bond_step(P, b, k, step++, lds); }
+        else { for (int k = P.k_first; k >= P.k_last; --k) wg_bond_step(P, b, k, step++, lds); }
         return;
     }
     for (int sw = 0; sw < P.sweeps; ++sw) {

@@ -5,7 +5,7 @@ recurrences (dot, orthogonalize, tt_compress!) are sequential only WITHIN a trai
 trains shards across ranks with no data-path collective (SURVEY §8e "replicas / trains in flight").
 torch.distributed (RCCL on GPUs, gloo in the CPU tests) is used only for barriers, the
 max-over-ranks timing reduction and gathering small per-train results (ranks, norms).
-Core-wise sharding of ONE long chain with neighbour hand-offs is the next row.
+Core-wise sharding of ONE long chain with neighbour hand-offs lives in pipeline.py.
 """
 from __future__ import annotations
 

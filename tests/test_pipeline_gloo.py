@@ -1,0 +1,135 @@
+"""Core-wise sharded tt_compress!(A*x, r) (tensortrainnumerics.jl_amd/pipeline.py): the chain is cut into
+`world` segments, one process per segment, boundary cores handed between neighbours over torch.distributed.
+
+* CPU (not gpu): the orchestration runs under gloo with the CPU oracle as compute backend
+  (tests/pipeline_oracle_backend.py); the union of the segments must equal the oracle's unsharded result.
+* GPU: the same with the HIP backend, two ranks sharing cuda:0 (gloo, boundary cores staged through the host), against
+  the single-process device result.  The nccl/xGMI transport differs only in where the tensors live."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(d, r, nmb, per_mb):
+    """Operator cores/ranks and nmb micro-batches of per_mb trains (seeds 30 + global index), as numpy."""
+    import ttn_amd as T
+    A = T.Delta(d)
+    mbs = []
+    g = 0
+    for _ in range(nmb):
+        trains = []
+        for _ in range(per_mb):
+            trains.append([np.asfortranarray(c) for c in T.rand_tt((2,) * d, r, seed=30 + g).ttv_vec])
+            g += 1
+        mbs.append(trains)
+    return [np.asfortranarray(c) for c in A.tto_vec], list(A.tto_rks), mbs
+
+
+def _worker(rank, world, port, use_gpu, d, r, nmb, per_mb, max_bond, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ttn_amd as T
+    from ttn_amd import pipeline as PL
+    if use_gpu:
+        backend = PL.DeviceBackend()
+    else:
+        from oracle import tt_oracle as O
+        from tests.pipeline_oracle_backend import OracleBackend
+        backend = OracleBackend(O)
+    A_cores, A_rks, mbs = _inputs(d, r, nmb, per_mb)
+    lo, hi = PL.extended_range(d, rank, world)
+    prepared = [backend.prepare(A_cores[lo:hi], A_rks[lo:hi + 1], [t[lo:hi] for t in trains], (2,) * (hi - lo)) for trains in mbs]
+    segs = PL.sharded_apply_compress(backend, PL.DistTransport(dist, "cpu"), rank, world, prepared, hi - lo, max_bond)
+    own0 = 0 if rank == 0 else 1                           # slot 0 of rank > 0 mirrors the neighbour's last core
+    out = [[backend.download(seg, b)[own0:] for b in range(per_mb)] for seg in segs]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, use_gpu, d, r, nmb, per_mb, max_bond):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, use_gpu, d, r, nmb, per_mb, max_bond, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    # glue the segments: result[mb][train] = list of d cores
+    glued = [[sum((res[rk][1][m][b] for rk in range(world)), []) for b in range(per_mb)] for m in range(nmb)]
+    return glued
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_core_sharded_compress_equals_unsharded_oracle(world):
+    from oracle import tt_oracle as O
+    d, r, nmb, per_mb = 9, 4, 2, 2
+    glued = _run(world, False, d, r, nmb, per_mb, r)
+    A_cores, A_rks, mbs = _inputs(d, r, nmb, per_mb)
+    A = O.TToperator(d, A_cores, (2,) * d, A_rks, [0] * d)
+    for m in range(nmb):
+        for b in range(per_mb):
+            x = O.TTvector(d, mbs[m][b], (2,) * d, [1] + [int(c.shape[2]) for c in mbs[m][b]], [0] * d)
+            y = O.tt_compress_(O.apply(A, x), r)
+            got = glued[m][b]
+            assert len(got) == d
+            assert [int(c.shape[2]) for c in got] == list(y.ttv_rks[1:])
+            for k in range(d):                              # same bond steps in the same order: identical cores
+                np.testing.assert_allclose(got[k], y.ttv_vec[k], rtol=0, atol=1e-13)
+
+
+def test_segment_bounds():
+    from ttn_amd import pipeline as PL
+    for d, w in ((30, 8), (30, 4), (9, 3), (5, 5), (7, 1)):
+        b = PL.segment_bounds(d, w)
+        assert b[0][0] == 0 and b[-1][1] == d and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert all(hi > lo for lo, hi in b)
+        for p in range(w):
+            lo, hi = PL.extended_range(d, p, w)
+            assert lo == b[p][0] - (1 if p else 0) and hi == b[p][1]
+
+
+@pytest.mark.gpu
+def test_core_sharded_compress_on_gpu_equals_single_process():
+    """Two ranks on one GPU (gloo transport): the sharded device result equals the unsharded device result."""
+    import ttn_amd as T
+    from ttn_amd import device as D
+    world, d, r, nmb, per_mb = 2, 16, 16, 2, 3
+    glued = _run(world, True, d, r, nmb, per_mb, r)
+    A = T.Delta(d)
+    dA = T.DeviceTTO(A)
+    g = 0
+    for m in range(nmb):
+        for b in range(per_mb):
+            x = T.rand_tt((2,) * d, r, seed=30 + g)
+            g += 1
+            dx = T.DeviceTT.from_host(x)
+            dy = T.DeviceTT((2,) * d, [a * c for a, c in zip(A.tto_rks, x.ttv_rks)])
+            D.apply(dA, dx, dy)
+            D.tt_compress_(dy, r)
+            y = dy.download(0)
+            got = glued[m][b]
+            assert [int(c.shape[2]) for c in got] == list(y.ttv_rks[1:])
+            for k in range(d):
+                np.testing.assert_allclose(got[k], y.ttv_vec[k], rtol=0, atol=1e-12)
