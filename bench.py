@@ -212,10 +212,10 @@ def main():
             dist.barrier()
 
     def step(i=None):
-        D.apply(dA, dx, dy)
+        # ttn_apply_compress: apply fused into the first L->R sweep of k_compress (y = A*x never exists in HBM)
         if i is not None:
             D.event_record(2 * i)
-        D.tt_compress_(dy, r)
+        D.apply_compress(dA, dx, dy, r)
         if i is not None:
             D.event_record(2 * i + 1)
 
@@ -243,12 +243,12 @@ def main():
         sx = T.DeviceTT.from_host(x0)
         sy = T.DeviceTT((2,) * d, ycap)
         for _ in range(2):
-            D.apply(dA, sx, sy); D.tt_compress_(sy, r)
+            D.apply_compress(dA, sx, sy, r)
         D.sync()
         ts = time.perf_counter()
         nrep = 5
         for _ in range(nrep):
-            D.apply(dA, sx, sy); D.tt_compress_(sy, r)
+            D.apply_compress(dA, sx, sy, r)
         D.sync()
         tsingle = (time.perf_counter() - ts) / nrep
         single = {"value": round(d / tsingle, 1), "unit": "TT cores/s", "ms_per_step": round(tsingle * 1e3, 3), "batch": 1}

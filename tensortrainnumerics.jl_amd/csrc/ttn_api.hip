@@ -621,7 +621,7 @@ int ttn_compress_rank_bound(int64_t d, const int64_t* dims, const int64_t* rks, 
 }
 
 static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, double truncerr, int64_t sweeps,
-                           int64_t k_first = 0, int64_t k_last = 0) {
+                           int64_t k_first = 0, int64_t k_last = 0, ttn_tto_t fuseA = nullptr, ttn_tt_t fusex = nullptr) {
     const int d = psi->d;
     if (d < 2 && k_single == 0) return TTN_OK;
     std::vector<int64_t> need, fin;
@@ -658,6 +658,9 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     P.sv_steps = steps;
     P.status = g_status;
     P.sweep_stats = g_status + psi->batch;
+    P.fused = (fuseA && fusex) ? 1 : 0;
+    if (P.fused) { P.op = fuseA->dev(); P.x = fusex->dev(); }
+    else { memset(&P.op, 0, sizeof(P.op)); memset(&P.x, 0, sizeof(P.x)); }
     P.prof = nullptr;
     if (getenv("TTN_PROF")) {
         static long long* d_prof = nullptr; static int prof_cap = 0;
@@ -744,10 +747,28 @@ int ttn_tt_core_import(ttn_tt_t h, int64_t k, const double* dev_buf, const int64
 
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
     if (sweeps < 1) return fail(TTN_ERR_SWEEPS, "sweeps must be >= 1");
-    int rc = ttn_apply(A, x, y);
-    if (rc) return rc;
-    return ttn_compress(y, max_bond, truncerr, sweeps);
+    if (!A || !x || !y) return fail(TTN_ERR_ARG, "null handle");
+    if (max_bond < 1) return fail(TTN_ERR_ARG, "max_bond must be >= 1");
+    const char* nf = getenv("TTN_NOFUSE");
+    if (x->d < 2 || (nf && atoi(nf))) {                     // nothing to fuse into / diagnostic switch
+        int rc = ttn_apply(A, x, y);
+        if (rc) return rc;
+        return ttn_compress(y, max_bond, truncerr, sweeps);
+    }
+    // FUSED: y = A*x is never written to HBM.  y only receives its ranks (A.rks .* x.rks, tt_operations.jl:103); the first
+    // L->R sweep of k_compress builds each merged matrix straight from core k of y, x_{k+1} and A_{k+1}.
+    if (!same_dims(A->dims, x->dims) || !same_dims(x->dims, y->dims)) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    if (x->batch != y->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
+    if (x == y) return fail(TTN_ERR_ARG, "ttn_apply_compress: output must not alias the input");
+    const int d = x->d;
+    for (int m = 0; m <= d; ++m) if (y->cap[m] < A->rks[m] * x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_apply: destination capacity too small");
+    hipLaunchKernelGGL(k_ranks_mul_op, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), A->dev(), x->dev());
+    HIPCHK(hipGetLastError());
+    for (int m = 0; m <= d; ++m) y->bound[m] = A->rks[m] * x->bound[m];
+    std::fill(y->ot.begin(), y->ot.end(), 0);
+    return launch_compress(y, 0, max_bond, truncerr, sweeps, 0, 0, A, x);
 }
 
 // status of the last dense kernel (synchronises): returns TTN_ERR_NO_CONVERGENCE if any train failed

@@ -10,8 +10,6 @@
 #include "ttn_common.h"
 #include <float.h>
 
-#define GEMM_BM (32 * (TTN_NWAVES / 4))   // 4 wave columns x (nwaves/4) wave rows, 32x32 per wave
-#define GEMM_BN 128
 #define GEMM_BK 16
 // LDS leading dimension (doubles) of the staged chunks, 145 = 17 mod 32.  Two access patterns meet here:
 //  * a k-fast operand is staged by 16 lanes that walk k (coalesced global reads) and store to As[kk*LD + r]: an even LD
@@ -20,7 +18,6 @@
 //  * the MFMA fragment reads take two k-rows per 32-lane half (ds_read_b64, 64 banks): LD*8 mod 256 = 136 puts the second
 //    row 2 banks short of the other half: one 2-way conflict per read instead of none.
 #define GEMM_LD 145
-#define GEMM_TILE_DOUBLES (2 * GEMM_BK * GEMM_LD)   // one LDS stage (A and B chunk) of the tiled (big) GEMM; it keeps two
 #define GEMM_LDS_DOUBLES (128 * 128 + 512)         // LDS region every GEMM may use (the one-shot small GEMM uses all of it): the 128x128
                                                    // Jacobi image + room for the odd leading dimensions of a 64x64x128 one-shot product
 // Call-boundary policy of the big building blocks (experiments: -DTTN_NI_JACOBI=inline etc.)
@@ -130,12 +127,20 @@ __device__ inline void gemm_publish_amax(const GemmDesc* dsc, double cmax) {
     }
 }
 
+// WR = wave rows of the 16-wave grid (WR x 16/WR waves, 32x32 outputs per wave): 4 -> 128x128 output tiles, 2 -> 64x256
+// (for m <= 64 and wide n, where half the waves of the square grid would idle).
+template <int WR>
 __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
+    constexpr int WCN = TTN_NWAVES / WR;                 // wave columns
+    constexpr int BM = 32 * WR, BN = 32 * WCN;
+    constexpr int LDA = GEMM_LD, LDB = (BN <= 128) ? GEMM_LD : 273;     // both == 17 mod 32 (see GEMM_LD)
+    constexpr int STAGE = GEMM_BK * (LDA + LDB);
+    static_assert(2 * STAGE <= GEMM_LDS_DOUBLES, "two LDS stages must fit");
     const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
     const View A = uniView(dsc->A), B = uniView(dsc->B), C = uniView(dsc->C);
     const double alpha = unif64(dsc->alpha), beta = unif64(dsc->beta);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WCN, wc = wave % WCN;
     const int li = lane & 15, lk = lane >> 4;
     gmem_f64* Ag = (gmem_f64*)A.p;
     gmem_f64* Bg = (gmem_f64*)B.p;
@@ -144,23 +149,23 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
     const bool a_kfast = minstride(A.c) < minstride(A.r);
     const bool b_kfast = minstride(B.r) < minstride(B.c);
     // staging assignment: element e = tid + TTN_WG*u of the BM x BK (A) and BK x BN (B) chunk
-    constexpr int NUA = GEMM_BM * GEMM_BK / TTN_WG, NUB = GEMM_BN * GEMM_BK / TTN_WG;
+    constexpr int NUA = BM * GEMM_BK / TTN_WG, NUB = BN * GEMM_BK / TTN_WG;
     int ar[NUA], akk[NUA], bc[NUB], bkk[NUB];
 #pragma unroll
     for (int u = 0; u < NUA; ++u) {
         const int e = tid + TTN_WG * u;
-        if (a_kfast) { akk[u] = e & (GEMM_BK - 1); ar[u] = e / GEMM_BK; } else { ar[u] = e & (GEMM_BM - 1); akk[u] = e / GEMM_BM; }
+        if (a_kfast) { akk[u] = e & (GEMM_BK - 1); ar[u] = e / GEMM_BK; } else { ar[u] = e & (BM - 1); akk[u] = e / BM; }
     }
 #pragma unroll
     for (int u = 0; u < NUB; ++u) {
         const int e = tid + TTN_WG * u;
-        if (b_kfast) { bkk[u] = e & (GEMM_BK - 1); bc[u] = e / GEMM_BK; } else { bc[u] = e & (GEMM_BN - 1); bkk[u] = e / GEMM_BN; }
+        if (b_kfast) { bkk[u] = e & (GEMM_BK - 1); bc[u] = e / GEMM_BK; } else { bc[u] = e & (BN - 1); bkk[u] = e / BN; }
     }
     double cmax = 0.0;
     const int nch = (k + GEMM_BK - 1) / GEMM_BK;
     int slab0 = -1;                                               // first k index the tables currently hold
-    for (int m0 = 0; m0 < m; m0 += GEMM_BM) {
-        for (int n0 = 0; n0 < n; n0 += GEMM_BN) {
+    for (int m0 = 0; m0 < m; m0 += BM) {
+        for (int n0 = 0; n0 < n; n0 += BN) {
             long long aoff[NUA], boff[NUB];
             bool aok[NUA], bok[NUB];
 #pragma unroll
@@ -208,10 +213,10 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
             }
 #define GEMM_STORE(STG)                                                                                         \
             {                                                                                                   \
-                lds_f64* As_ = (lds_f64*)lds + (STG) * GEMM_TILE_DOUBLES;                                       \
-                lds_f64* Bs_ = As_ + GEMM_BK * GEMM_LD;                                                         \
-                _Pragma("unroll") for (int u = 0; u < NUA; ++u) As_[akk[u] * GEMM_LD + ar[u]] = av[u];          \
-                _Pragma("unroll") for (int u = 0; u < NUB; ++u) Bs_[bkk[u] * GEMM_LD + bc[u]] = bv[u];          \
+                lds_f64* As_ = (lds_f64*)lds + (STG) * STAGE;                                                    \
+                lds_f64* Bs_ = As_ + GEMM_BK * LDA;                                                             \
+                _Pragma("unroll") for (int u = 0; u < NUA; ++u) As_[akk[u] * LDA + ar[u]] = av[u];              \
+                _Pragma("unroll") for (int u = 0; u < NUB; ++u) Bs_[bkk[u] * LDB + bc[u]] = bv[u];              \
             }
             if (slab0 != 0) GEMM_FILL_TAB(0)
             else __syncthreads();                      // the previous tile's MFMAs have consumed both stages
@@ -226,33 +231,22 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
                 // The staging work of the other chunks is placed BETWEEN this wave's MFMA groups: an MFMA occupies the
                 // matrix pipe for 64 clk, so the VALU/LDS/global instructions issued behind it run under the MFMAs of
                 // the SIMD's other waves instead of after them (the waves run in lockstep from barrier to barrier).
-                lds_f64* As = (lds_f64*)lds + (c & 1) * GEMM_TILE_DOUBLES;
-                lds_f64* Bs = As + GEMM_BK * GEMM_LD;
-#ifdef GEMM_EXP_NOLDS
-#define GEMM_EXP_READS const double a0 = alpha + kr, a1 = alpha - kr, b0 = beta + kr, b1 = beta - kr;
-#else
-#define GEMM_EXP_READS const double a0 = As[kr + wr * 32 + li], a1 = As[kr + wr * 32 + 16 + li]; const double b0 = Bs[kr + wc * 32 + li], b1 = Bs[kr + wc * 32 + 16 + li];
-#endif
+                lds_f64* As = (lds_f64*)lds + (c & 1) * STAGE;
+                lds_f64* Bs = As + GEMM_BK * LDA;
 #define GEMM_MFMA_STEP(T)                                                                                       \
                 if (live) {                                                                                     \
-                    const int kr = (4 * (T) + lk) * GEMM_LD;                                                    \
-                    GEMM_EXP_READS                                                                              \
+                    const int kra = (4 * (T) + lk) * LDA, krb = (4 * (T) + lk) * LDB;                                                 \
+                    const double a0 = As[kra + wr * 32 + li], a1 = As[kra + wr * 32 + 16 + li];                 \
+                    const double b0 = Bs[krb + wc * 32 + li], b1 = Bs[krb + wc * 32 + 16 + li];                 \
                     acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);               \
                     acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);               \
                     acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);               \
                     acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);               \
                 }
                 GEMM_MFMA_STEP(0)
-#if !defined(GEMM_EXP_NOSTAGE) && !defined(GEMM_EXP_NOSTORE)
                 if (c + 1 < nch) GEMM_STORE((c + 1) & 1)
-#endif
                 GEMM_MFMA_STEP(1)
-#if !defined(GEMM_EXP_NOSTAGE) && !defined(GEMM_EXP_NOLOAD)
-                if (c + 2 < nch)
-#else
-                if (false)
-#endif
-                {
+                if (c + 2 < nch) {
                     const int k2 = (c + 2) * GEMM_BK;
                     if (k2 >= slab0 + GEMM_KSLAB) GEMM_FILL_TAB(k2)       // workgroup-uniform; rare (k > GEMM_KSLAB)
                     GEMM_LOAD(k2)
@@ -432,8 +426,10 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
             __syncthreads();
             wg_gemm_small_impl(dsc, lds);
         }
+    } else if (m <= 64 && n > 128) {
+        wg_gemm_impl<2>(dsc, lds);                       // 64 x 256 output tiles: all 16 waves busy on a short, wide product
     } else {
-        wg_gemm_impl(dsc, lds);
+        wg_gemm_impl<4>(dsc, lds);
     }
 }
 
@@ -1097,6 +1093,11 @@ struct CompressArgs {
     long long* prof;       // null, or cycle counters per phase (TTN_PROF=1 diagnostic launches only)
     double jneg_mult;      // columns below jneg_mult * sqrt(m) * eps * max column norm are treated as zero
     int fast;              // 1: try the Gram/Cholesky fast paths (verified a posteriori) before Householder
+    // fused apply (ttn_apply_compress): psi = A * x is never materialised.  During the FIRST L->R sweep core k+1 of psi
+    // is still virtual (= A_{k+1} applied to x_{k+1}); psi's ranks already hold A.rks .* x.rks.
+    int fused;
+    TTODev op;
+    TTDev x;
 };
 
 #define COMPRESS_LDS_X_DOUBLES (128 * 128)
@@ -1174,6 +1175,96 @@ __device__ double wg_check_diag(const BondCtx& S, const double* D, int ldd, int 
     return wg_max(worst, S.red);
 }
 
+// Core k of psi = A * x written out (src/tt_operations.jl:101-111): psi_k[s, a' + Rl*nu', a + Rr*nu] = sum_j A_k[s,j,a',a] x_k[j,nu',nu].
+// Used by the fused apply+compress for the cores the fused merge does not cover (first core, tall / tiny steps).
+__device__ void wg_materialize_core(const CompressArgs& P, int b, int k) {
+    const TTDev& T = P.tt;
+    const int n = T.dims[k];
+    const long long* xr = P.x.rks + (long long)b * (P.x.d + 1);
+    const int rl = (int)xr[k], rr = (int)xr[k + 1];
+    const int Rl = (int)P.op.rks[k], Rr = (int)P.op.rks[k + 1];
+    const double* xc = P.x.data + (long long)b * P.x.stride + P.x.off[k];
+    const double* ac = P.op.data + P.op.off[k];
+    double* yc = T.data + (long long)b * T.stride + T.off[k];
+    const long long Dl = (long long)Rl * rl, tot = (long long)n * Dl * Rr * rr;
+    for (long long e = threadIdx.x; e < tot; e += TTN_WG) {
+        const int s = (int)(e % n);
+        const long long t1 = e / n;
+        const int ga = (int)(t1 % Dl), be = (int)(t1 / Dl);
+        const int a1 = ga % Rl, nu1 = ga / Rl, a2 = be % Rr, nu2 = be / Rr;
+        double v = 0.0;
+        for (int j = 0; j < n; ++j)
+            v = fma(ac[s + n * (j + n * (a1 + (long long)Rl * a2))], xc[j + n * (nu1 + (long long)rl * nu2)], v);
+        yc[e] = v;
+    }
+    __syncthreads();
+}
+
+// Fused merge of an L->R step whose right core is still virtual (wide case, p = n1*Dl rows):
+//   M[row, s2 + n2*(a + Rr*nu)] = sum_{a', nu'} C_k[row, a' + Rl*nu'] * sum_j A[s2, j, a', a] x[j, nu', nu]
+// = (i)  T_a'[row, (j, nu)] = sum_nu' C_k[row, a' + Rl*nu'] x[j, nu', nu]      Rl GEMMs  p x (n2*rho_r) x rho_l  (MFMA)
+//   (ii) M[row, (s2, a, nu)] = sum_{a', j} T_a'[row, (j, nu)] A[s2, j, a', a]     Rl*n2 terms per output     (VALU)
+// 2*p*Rl*rho_l*n2*rho_r flops instead of 2*p*(Rl*rho_l)*(n2*Rr*rho_r) — Rr times fewer — and the core never exists in HBM.
+// T lives in `Tbuf` (>= Rl*p*n2*rho_r doubles).  max|M| goes to *amax_lds.  Returns false (nothing done) if the shapes
+// do not qualify; the caller then materialises the core.
+#define FUSE_MAX_TERMS 16
+__device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q, const View& Am, double* M, double* Tbuf,
+                               long long tbuf_doubles, double* lds, double* amax_lds, double* red) {
+    const TTDev& T = P.tt;
+    const int n1 = T.dims[k], n2 = T.dims[k + 1];
+    const long long* rks = T.rks + (long long)b * (T.d + 1);
+    const int Dl = (int)rks[k];
+    const long long* xr = P.x.rks + (long long)b * (P.x.d + 1);
+    const int rhl = (int)xr[k + 1], rhr = (int)xr[k + 2];
+    const int Rl = (int)P.op.rks[k + 1], Rr = (int)P.op.rks[k + 2];
+    const int ncol = n2 * rhr;
+    if (Rl * n2 > FUSE_MAX_TERMS || n2 * Rr > FUSE_MAX_TERMS || (long long)Rl * p * ncol > tbuf_doubles) return false;
+    if ((long long)Rl * rhl != rks[k + 1] || (long long)n2 * Rr * rhr != q || p != n1 * Dl) return false;
+    double* ck = T.data + (long long)b * T.stride + T.off[k];
+    double* xc = P.x.data + (long long)b * P.x.stride + P.x.off[k + 1];
+    const double* ac = P.op.data + P.op.off[k + 1];
+    const long long ldk = (long long)n1 * Dl;                           // column stride of C_k viewed as (n1*Dl) x r_mid
+    for (int a1 = 0; a1 < Rl; ++a1) {
+        const View Av = mkview(ck + a1 * ldk, Am.r, plain((long long)Rl * ldk));
+        const View Bv = mkview(xc, plain(n2), Idx{n2, 1, (long long)n2 * rhl});
+        const View Cv = mkview(Tbuf + (long long)a1 * p * ncol, plain(ncol), plain(1));
+        wg_gemm(p, ncol, rhl, Av, Bv, Cv, 1.0, 0.0, lds);
+    }
+    // (ii): one thread per (row, nu): Rl*n2 inputs, n2*Rr outputs.  The operator core is staged in LDS as opl[o*nin + i]
+    // (o = s2 + n2*a, i = j + n2*a'; the GEMM region is free between GEMM calls): the inner product then costs one broadcast
+    // LDS read and one FMA per term instead of an indexed global load.
+    double mx = 0.0;
+    const int nin = Rl * n2, nout = n2 * Rr;
+    lds_f64* opl = (lds_f64*)lds;
+    for (int e = threadIdx.x; e < nin * nout; e += TTN_WG) {
+        const int i = e % nin, o = e / nin;
+        opl[e] = ac[(o % n2) + n2 * ((i % n2) + n2 * ((i / n2) + (long long)Rl * (o / n2)))];
+    }
+    __syncthreads();
+    const long long tstride = (long long)p * ncol;                          // doubles between T_a' and T_a'+1
+    for (int e = threadIdx.x; e < p * rhr; e += TTN_WG) {
+        const int nu = e % rhr, row = e / rhr;
+        const double* tp = Tbuf + (long long)row * ncol + n2 * nu;
+        double t[FUSE_MAX_TERMS];
+#pragma unroll
+        for (int i = 0; i < FUSE_MAX_TERMS; ++i) t[i] = (i < nin) ? tp[(i / n2) * tstride + (i % n2)] : 0.0;
+        double* mrow = M + (long long)row * q + (long long)nout * nu;
+        for (int o = 0; o < nout; ++o) {
+            const lds_f64* w = opl + o * nin;
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < FUSE_MAX_TERMS; ++i)
+                if (i < nin) v = fma(t[i], w[i], v);
+            mrow[o] = v;
+            mx = fmax(mx, fabs(v));
+        }
+    }
+    mx = wg_max(mx, red);
+    if (threadIdx.x == 0) *amax_lds = mx;
+    __syncthreads();
+    return true;
+}
+
 // One bond step on (core_k, core_{k+1}), 0-based k.  src/tt_tools.jl:743-768 with the effective
 // _svdtrunc of src/tt_cross_interpolation.jl:149-166.
 //
@@ -1185,7 +1276,7 @@ __device__ double wg_check_diag(const BondCtx& S, const double* D, int ldd, int 
 //   H            robust: blocked Householder LQ of M (or M itself if square), Jacobi on its columns.
 // F and G square the condition number, so they are taken only if sigma_max/sigma_min <= FAST_KAPPA_MAX and are
 // verified a posteriori (Rf Rf^T = Sigma, Lf^T Lf = Sigma to FAST_CHECK_TOL); otherwise the step is redone by H.
-__device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, double* lds) {
+__device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, double* lds, bool virt = false /* core k+1 is A_{k+1} x_{k+1}, not yet written */) {
     const int tid = threadIdx.x;
     const TTDev& T = P.tt;
     long long* rks = T.rks + (long long)b * (T.d + 1);
@@ -1228,6 +1319,14 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
     S.T1 = S.Cc + 128 * 128;
     S.T2 = S.T1 + 128 * 128;
     S.T3 = S.T2 + 128 * 128;
+
+    // fused apply: the right core is still A_{k+1} x_{k+1}.  Wide steps with r_mid >= p get the fused merge below; the
+    // others (first steps of the ramp that are tall, tiny cores) write the core out first and proceed as usual.
+    bool virt_live = false;
+    if (virt) {
+        if (wide && rm >= p) virt_live = true;
+        else wg_materialize_core(P, b, k + 1);
+    }
 
     long long t_prev = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define PROF_MARK(slot) if (P.prof) { __syncthreads(); if (tid == 0) { long long t_now = (long long)__builtin_amdgcn_s_memtime(); P.prof[(long long)b * 16 + (slot)] += t_now - t_prev; t_prev = t_now; } }
@@ -1346,7 +1445,12 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
         const View Mv = mkview(S.M, plain(q), plain(1));
         // M stays UNSCALED in memory: max|M| comes out of the GEMM epilogue and the consumers (Gram, LQ copy, output GEMM)
         // apply 1/s0 as their alpha — no extra read-modify-write pass over the p x q matrix.
-        wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds, S.scal + 6);
+        bool merged = false;
+        if (virt_live) {
+            merged = wg_fused_merge(P, b, k, p, q, Am, S.M, S.M2, pq, lds, S.scal + 6, S.red);
+            if (!merged) wg_materialize_core(P, b, k + 1);
+        }
+        if (!merged) wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds, S.scal + 6);
         PROF_MARK(0)
         const double mx = S.scal[6];
         const double s0 = (mx > 0.0) ? mx : 1.0;
@@ -1469,8 +1573,9 @@ __global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {
         else { for (int k = P.k_first; k >= P.k_last; --k) wg_bond_step(P, b, k, step++, lds); }
         return;
     }
+    if (P.fused) wg_materialize_core(P, b, 0);
     for (int sw = 0; sw < P.sweeps; ++sw) {
-        for (int k = 0; k < d - 1; ++k) wg_bond_step(P, b, k, step++, lds);
+        for (int k = 0; k < d - 1; ++k) wg_bond_step(P, b, k, step++, lds, P.fused && sw == 0);
         for (int k = d - 2; k >= 0; --k) wg_bond_step(P, b, k, step++, lds);
     }
 }

@@ -13,9 +13,9 @@ for b in range(B):
     dx.upload(b, T.rand_tt((2,) * d, r, seed=30 + b))
 dy = T.DeviceTT((2,) * d, [a * c for a, c in zip(A.tto_rks, x0.ttv_rks)], batch=B)
 for it in range(2):
-    D.apply(dA, dx, dy); D.sync()
+    D.sync()
     t0 = time.perf_counter()
-    D.tt_compress_(dy, r); D.sync()
+    D.apply_compress(dA, dx, dy, r); D.sync()        # fused (TTN_NOFUSE=1: apply, then compress)
     t1 = time.perf_counter()
     try:
         sw = D.compress_status(dy); ok = True

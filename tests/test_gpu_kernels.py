@@ -27,7 +27,7 @@ def _gemm(T, A, B, C0, alpha, beta, ta, tb):
 
 
 @pytest.mark.parametrize("m,n,k", [(16, 16, 4), (32, 32, 16), (128, 128, 16), (128, 384, 192), (1, 1, 1), (17, 33, 5),
-                                   (130, 70, 37), (64, 200, 129), (3, 300, 2)])
+                                   (130, 70, 37), (64, 200, 129), (3, 300, 2), (64, 384, 128), (40, 520, 800), (192, 192, 1000)])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 def test_wg_gemm_exact_on_integers(T, m, n, k, ta, tb):
     rng = np.random.default_rng(m * 1000 + n * 10 + k)

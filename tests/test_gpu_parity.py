@@ -518,6 +518,39 @@ def test_fast_routes_agree_with_robust_route(T, monkeypatch):
     assert tt_rel_diff(to_oracle(fast), to_oracle(robust)) <= 1e-10
 
 
+@pytest.mark.parametrize("dims,oprks,xr,mb", [((2,) * 30, None, 64, 64), ((2, 3, 2, 2, 3, 2, 2), [1, 2, 3, 2, 4, 2, 3, 1], 5, 6),
+                                              ((4, 2, 3, 4, 2), [1, 3, 2, 2, 3, 1], 7, 9)])
+def test_fused_apply_compress_equals_apply_then_compress(T, monkeypatch, dims, oprks, xr, mb):
+    """ttn_apply_compress never writes A*x (the first L->R sweep builds each merged matrix from core k, x_{k+1}, A_{k+1});
+    TTN_NOFUSE=1 runs apply and compress separately.  Same ranks, tensors to 1e-10; general dims / operator ranks too,
+    and the unfused result is pinned to the oracle."""
+    d = len(dims)
+    rng = np.random.default_rng(7)
+    if oprks is None:
+        A = T.Delta(d)
+    else:
+        A = T.TToperator(d, [np.asfortranarray(rng.standard_normal((dims[k], dims[k], oprks[k], oprks[k + 1]))) for k in range(d)],
+                         dims, oprks, [0] * d)
+    x = T.rand_tt(dims, xr, seed=11)
+    B = 3
+    dA, dx = T.DeviceTTO(A), T.DeviceTT.from_host(x, batch=B)
+    cap = [a * c for a, c in zip(A.tto_rks, x.ttv_rks)]
+    y1, y2 = T.DeviceTT(dims, cap, batch=B), T.DeviceTT(dims, cap, batch=B)
+    T.device.apply_compress(dA, dx, y1, mb)
+    T.device.compress_status(y1)
+    monkeypatch.setenv("TTN_NOFUSE", "1")
+    T.device.apply_compress(dA, dx, y2, mb)
+    T.device.compress_status(y2)
+    monkeypatch.delenv("TTN_NOFUSE")
+    ref = O.tt_compress_(O.apply(to_oracle(A), to_oracle(x)), mb) if d <= 12 else None
+    for b in (0, B - 1):
+        f, u = y1.download(b), y2.download(b)
+        assert f.ttv_rks == u.ttv_rks
+        assert tt_rel_diff(to_oracle(f), to_oracle(u)) <= 1e-10
+        if ref is not None:
+            assert u.ttv_rks == ref.ttv_rks and tt_rel_diff(to_oracle(u), ref) <= 1e-9
+
+
 # ------------------------------------------------------------------------------------------------
 # device-resident caller chains (SURVEY §8 f3): rk4_method / euler_method of src/solvers/euler.jl on handles
 # ------------------------------------------------------------------------------------------------
