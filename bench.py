@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="independent trains per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="independent trains per GPU per step (4 per CU: the hardware dispatcher then balances the 498-570 Jacobi sweeps per train)")
     ap.add_argument("--d", type=int, default=30)
     ap.add_argument("--rank", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -261,8 +261,8 @@ def main():
         # HBM traffic of the dominant kernel comes from the committed rocprofv3 PMC passes of THIS command line
         # (counters cannot be read from inside the process); only reported when the configuration matches.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01d_k_compress_traffic.json")
-        if os.path.exists(tpath) and (d, r, B, world) == (30, 64, 256, 1):
+        tpath = os.path.join(ROOT, "profiles", "r01e_k_compress_traffic.json")
+        if os.path.exists(tpath) and (d, r, B, world) == (30, 64, 1024, 1):
             with open(tpath) as fh:
                 traffic = json.load(fh)["traffic_bytes_per_launch_upper"]
         res = {

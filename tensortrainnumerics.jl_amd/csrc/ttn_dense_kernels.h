@@ -967,17 +967,8 @@ __device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* f
     __syncthreads();
     double pmin = dmax;                                  // tracked by wave 0 (every lane sees every pivot)
     int bad = 0;
-#ifdef CHOL_PROF
-    long long cp_[4] = {0, 0, 0, 0};
-#define CPM(k) { const long long t_ = __builtin_amdgcn_s_memtime(); cp_[k] += t_ - cpt_; cpt_ = t_; }
-#else
-#define CPM(k)
-#endif
     for (int j0 = 0; j0 < n; j0 += 16) {
         const int jb = (n - j0 < 16) ? n - j0 : 16;
-#ifdef CHOL_PROF
-        long long cpt_ = __builtin_amdgcn_s_memtime();
-#endif
         // ---- (a) diagonal block, wave 0, in REGISTERS: lane (li, lk) holds D[li][lk + 4q], q = 0..3.  Per column one LDS
         //      round trip: the owners publish the unscaled column, every lane reads the pivot, its row's and its columns'
         //      entries and applies the rank-1 update to its four elements ----
@@ -1015,7 +1006,6 @@ __device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* f
             for (int q = 0; q < 4; ++q) { const int c = lk + 4 * q; if (li < jb && c <= li) D[c * 128 + li] = e[q]; }
         }
         __syncthreads();
-        CPM(0)
         if (*flag) { bad = 1; break; }
         const int s0 = j0 + jb, sr = n - s0;             // first row / number of rows below the block
         if (sr > 0) {                                    // then jb == 16
@@ -1035,7 +1025,6 @@ __device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* f
                 for (int c = 0; c < 16; ++c) G[(j0 + c) * 128 + r] = a[c];
             }
             __syncthreads();
-            CPM(1)
             // ---- (c) trailing update, lower-triangle tiles (tr >= tc) ----
             const int nt = (sr + 15) >> 4, ntiles = nt * (nt + 1) / 2;
             for (int tile = wave; tile < ntiles; tile += nwaves) {
@@ -1058,13 +1047,8 @@ __device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* f
                 }
             }
             __syncthreads();
-            CPM(2)
         }
     }
-#ifdef CHOL_PROF
-    if (tid == 0) { pivmin_out[2] += (double)cp_[0]; pivmin_out[3] += (double)cp_[1]; pivmin_out[4] += (double)cp_[2]; }
-#endif
-#undef CPM
     // pivots lie between the extreme eigenvalues of G, so dmax/pmin is a LOWER bound of cond(G) = cond(M)^2
     if (tid == 0) *pivmin_out = (!bad && pmin > 0.0) ? dmax / pmin : 1.0e300;
     for (int e = tid; e < n * 128; e += TTN_WG) { const int c = e >> 7, i = e & 127; if (i < c) G[c * 128 + i] = 0.0; }
@@ -1661,7 +1645,6 @@ __global__ void __launch_bounds__(TTN_WG) k_bench_lds(int what, int n, int reps,
     int* iflag = (int*)(scal + 8);
     double* nrm2 = scal + 16;
     int sw = 0;
-    if (threadIdx.x < 8) scal[threadIdx.x] = 0.0;
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < reps; ++r) {
@@ -1675,10 +1658,5 @@ __global__ void __launch_bounds__(TTN_WG) k_bench_lds(int what, int n, int reps,
         __syncthreads();
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0) {
-        out[0] = t1 - t0; out[1] = sw;
-#ifdef CHOL_PROF
-        printf("chol phases (a) %.0f (b) %.0f (c) %.0f clk per call\n", scal[3] / reps, scal[4] / reps, scal[5] / reps);
-#endif
-    }
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = sw; }
 }
