@@ -1142,7 +1142,7 @@ __device__ int wg_rank_rule(const CompressArgs& P, const BondCtx& S, int ns, int
         S.iflag[1] = r;
     }
     __syncthreads();
-    const int r = S.iflag[1];
+    const int r = uni32(S.iflag[1]);
     __syncthreads();
     return r;
 }
@@ -1260,12 +1260,15 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
 //   H            robust: blocked Householder LQ of M (or M itself if square), Jacobi on its columns.
 // F and G square the condition number, so they are taken only if sigma_max/sigma_min <= FAST_KAPPA_MAX and are
 // verified a posteriori (Rf Rf^T = Sigma, Lf^T Lf = Sigma to FAST_CHECK_TOL); otherwise the step is redone by H.
-__device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, double* lds, bool virt = false /* core k+1 is A_{k+1} x_{k+1}, not yet written */) {
+__device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, double* lds, bool virt = false /* core k+1 is A_{k+1} x_{k+1}, not yet written */) {
     const int tid = threadIdx.x;
     const TTDev& T = P.tt;
     long long* rks = T.rks + (long long)b * (T.d + 1);
-    const int n1 = T.dims[k], n2 = T.dims[k + 1];
-    const int Dl = (int)rks[k], rm = (int)rks[k + 1], Dr = (int)rks[k + 2];
+    // the ranks are read from memory this kernel also writes, so the compiler treats them (and every view, size and pointer
+    // derived from them) as per-lane values: readfirstlane pins them to SGPRs — the bond step is full of calls, and every
+    // VGPR that is live across a call costs a slot of the stack frame (HBM traffic, profiles/README.md "traffic by step")
+    const int n1 = uni32(T.dims[k]), n2 = uni32(T.dims[k + 1]);
+    const int Dl = uni32((int)rks[k]), rm = uni32((int)rks[k + 1]), Dr = uni32((int)rks[k + 2]);
     const int mr = n1 * Dl, mc = n2 * Dr;
     double* ck = T.data + (long long)b * T.stride + T.off[k];
     double* ck1 = T.data + (long long)b * T.stride + T.off[k + 1];
@@ -1326,8 +1329,8 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
         double sa = 0.0, sb = 0.0;
         for (long long e = tid; e < (long long)n1 * Dl * rm; e += TTN_WG) sa = fmax(sa, fabs(ck[e]));
         for (long long e = tid; e < (long long)n2 * rm * Dr; e += TTN_WG) sb = fmax(sb, fabs(ck1[e]));
-        sa = wg_max(sa, S.red);
-        sb = wg_max(sb, S.red);
+        sa = unif64(wg_max(sa, S.red));
+        sb = unif64(wg_max(sb, S.red));
         bool ok = (sa > 0.0) && (sb > 0.0);
         const double sA = wide ? sa : sb, sB = wide ? sb : sa;       // scale of A', B'
         const double s0 = sA * sB;
@@ -1360,7 +1363,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             wg_gemm(rm, rm, rm, tview(Gav), Gbv, Ccv, 1.0, 0.0, lds);
             for (int e = tid; e < rm * 128; e += TTN_WG) { const int c = e >> 7, r_ = e & 127; S.ldsX[e] = (r_ < rm) ? S.Cc[c * 128 + r_] : 0.0; }
             __syncthreads();
-            const int nsw = wg_svd_cols(P, S, rm, S.ldsX, 128, true);
+            const int nsw = uni32(wg_svd_cols(P, S, rm, S.ldsX, 128, true));
             nsw_total += (nsw < 0 ? -nsw : nsw);
             ok = (nsw > 0) && (S.sigs[rm - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[rm - 1] * S.sigs[rm - 1] > S.scal[0]);
             PROF_MARK(10)
@@ -1436,7 +1439,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
         }
         if (!merged) wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds, S.scal + 6);
         PROF_MARK(0)
-        const double mx = S.scal[6];
+        const double mx = unif64(S.scal[6]);
         const double s0 = (mx > 0.0) ? mx : 1.0;
         const double inv_s0 = 1.0 / s0;
         PROF_MARK(1)
@@ -1477,7 +1480,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             }
             int nsw = 0;
             if (ok) {
-                nsw = wg_svd_cols(P, S, p, X, ldx, x_in_lds);
+                nsw = uni32(wg_svd_cols(P, S, p, X, ldx, x_in_lds));
                 nsw_total += (nsw < 0 ? -nsw : nsw);
                 if (attempt == 1) ok = nsw > 0;
                 else if (nsw < 0 && tid == 0) P.status[b] = 1;
@@ -1518,7 +1521,7 @@ __device__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, doub
             wg_gemm(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, Ro, inv_s0, 0.0, lds);
             if (attempt == 1) {
                 wg_gemm(r, r, q, Ro, tview(Ro), mkview(S.T2, plain(1), plain(128)), 1.0, 0.0, lds);
-                const double e2 = wg_check_diag(S, S.T2, 128, r, s0);
+                const double e2 = unif64(wg_check_diag(S, S.T2, 128, r, s0));
                 if (!(e2 <= FAST_CHECK_TOL)) continue;                     // redo with Householder (M is intact)
                 if (P.sv_out && step < P.sv_steps) {
                     double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
@@ -1547,20 +1550,24 @@ __global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {
     const int d = P.tt.d;
     if (threadIdx.x == 0) { P.status[b] = 0; P.sweep_stats[b] = 0; }
     __syncthreads();
-    int step = 0;
-    if (P.k_single > 0) {
-        wg_bond_step(P, b, P.k_single - 1, step, lds);
-        return;
-    }
-    if (P.k_single < 0) {                                   // one direction of a sweep over a segment (ttn_sweep)
-        if (P.k_first <= P.k_last) { for (int k = P.k_first; k <= P.k_last; ++k) wg_bond_step(P, b, k, step++, lds); }
-        else { for (int k = P.k_first; k >= P.k_last; --k) wg_bond_step(P, b, k, step++, lds); }
-        return;
-    }
     if (P.fused) wg_materialize_core(P, b, 0);
-    for (int sw = 0; sw < P.sweeps; ++sw) {
-        for (int k = 0; k < d - 1; ++k) wg_bond_step(P, b, k, step++, lds, P.fused && sw == 0);
-        for (int k = d - 2; k >= 0; --k) wg_bond_step(P, b, k, step++, lds);
+    // ONE call site of the (force-inlined) bond step: as an out-of-line function it received its arguments in VGPRs, so
+    // every size, view and pointer derived from them was a per-lane value and the step carried a 512-byte stack frame per
+    // lane across its ~25 calls.  Inlined here everything uniform sits in SGPRs.
+    const int per_sweep = 2 * (d - 1);
+    const int nsteps = (P.k_single > 0) ? 1 : (P.k_single < 0) ? ((P.k_first <= P.k_last ? P.k_last - P.k_first : P.k_first - P.k_last) + 1)
+                                                               : P.sweeps * per_sweep;
+    for (int step = 0; step < nsteps; ++step) {
+        int k;
+        bool virt = false;
+        if (P.k_single > 0) k = P.k_single - 1;                                  // _tt_bond_truncate!
+        else if (P.k_single < 0) k = (P.k_first <= P.k_last) ? P.k_first + step : P.k_first - step;     // ttn_sweep
+        else {                                                                   // tt_compress!: L->R then R->L per sweep
+            const int i = step % per_sweep;
+            k = (i < d - 1) ? i : per_sweep - 1 - i;
+            virt = P.fused && step < d - 1;                                      // first L->R sweep of the fused op
+        }
+        wg_bond_step(P, b, k, step, lds, virt);
     }
 }
 
