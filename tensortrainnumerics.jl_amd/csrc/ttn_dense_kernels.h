@@ -113,6 +113,7 @@ __device__ inline long long uni64(long long v) {
     const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
     return ((long long)hi << 32) | (unsigned int)lo;
 }
+template <typename PT> __device__ inline PT* unip(PT* q_) { return (PT*)uni64((long long)q_); }
 __device__ inline double unif64(double v) { union { double d; long long i; } u; u.d = v; u.i = uni64(u.i); return u.d; }
 __device__ inline Idx uniIdx(const Idx& d) { return Idx{uni32(d.q), uni64(d.lo), uni64(d.hi)}; }
 __device__ inline View uniView(const View& v) { return View{(double*)uni64((long long)v.p), uniIdx(v.r), uniIdx(v.c)}; }
@@ -494,6 +495,10 @@ __device__ inline double wave64_sum_fast(double v) {
 
 __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, double* Vb, double* Wb, double* Tst, double* Qout,
                                            double* lds_gemm, double* Ts, double* Ss, double* taus, double* red) {
+    // arguments of an out-of-line function arrive in VGPRs: pin the workgroup-uniform ones to SGPRs
+    p = uni32(p); q = uni32(q); ld = uni32(ld);
+    M2 = unip(M2); Vb = unip(Vb); Wb = unip(Wb); Tst = unip(Tst); Qout = unip(Qout);
+    lds_gemm = unip(lds_gemm); Ts = unip(Ts); Ss = unip(Ss); taus = unip(taus); red = unip(red);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
     const int rr = min(p, q);
     double* betas = Ss;                                  // QR_NB (Ss is free while a panel is being factored)
@@ -955,6 +960,7 @@ __device__ TTN_NI_JACOBI int wg_jacobi_lds128(int m, int p, double* Xg, double* 
 //       operands read straight from the LDS image.
 // -------------------------------------------------------------------------------------------------
 __device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
+    n = uni32(n); Gg = unip(Gg); red = unip(red); flag = unip(flag); pivmin_out = unip(pivmin_out);     // VGPR arguments -> SGPRs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
     const int li = lane & 15, lk = lane >> 4;
     lds_f64* G = (lds_f64*)Gg;
