@@ -1171,8 +1171,8 @@ __device__ void wg_materialize_core(const CompressArgs& P, int b, int k) {
     const TTDev& T = P.tt;
     const int n = T.dims[k];
     const long long* xr = P.x.rks + (long long)b * (P.x.d + 1);
-    const int rl = (int)xr[k], rr = (int)xr[k + 1];
-    const int Rl = (int)P.op.rks[k], Rr = (int)P.op.rks[k + 1];
+    const int rl = uni32((int)xr[k]), rr = uni32((int)xr[k + 1]);
+    const int Rl = uni32((int)P.op.rks[k]), Rr = uni32((int)P.op.rks[k + 1]);
     const double* xc = P.x.data + (long long)b * P.x.stride + P.x.off[k];
     const double* ac = P.op.data + P.op.off[k];
     double* yc = T.data + (long long)b * T.stride + T.off[k];
@@ -1203,10 +1203,10 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
     const TTDev& T = P.tt;
     const int n1 = T.dims[k], n2 = T.dims[k + 1];
     const long long* rks = T.rks + (long long)b * (T.d + 1);
-    const int Dl = (int)rks[k];
+    const int Dl = uni32((int)rks[k]);
     const long long* xr = P.x.rks + (long long)b * (P.x.d + 1);
-    const int rhl = (int)xr[k + 1], rhr = (int)xr[k + 2];
-    const int Rl = (int)P.op.rks[k + 1], Rr = (int)P.op.rks[k + 2];
+    const int rhl = uni32((int)xr[k + 1]), rhr = uni32((int)xr[k + 2]);
+    const int Rl = uni32((int)P.op.rks[k + 1]), Rr = uni32((int)P.op.rks[k + 2]);
     const int ncol = n2 * rhr;
     if (Rl * n2 > FUSE_MAX_TERMS || n2 * Rr > FUSE_MAX_TERMS || (long long)Rl * p * ncol > tbuf_doubles) return false;
     if ((long long)Rl * rhl != rks[k + 1] || (long long)n2 * Rr * rhr != q || p != n1 * Dl) return false;
@@ -1605,7 +1605,7 @@ __global__ void __launch_bounds__(TTN_WG) k_dot(DotArgs P) {
     double* Mc = M0; double* Mn = M1;
     for (int k = 0; k < A.d; ++k) {
         const int n = A.dims[k];
-        const int ra = (int)ar[k], ra2 = (int)ar[k + 1], rb = (int)br[k], rb2 = (int)br[k + 1];
+        const int ra = uni32((int)ar[k]), ra2 = uni32((int)ar[k + 1]), rb = uni32((int)br[k]), rb2 = uni32((int)br[k + 1]);
         double* Ak = A.data + (long long)t * A.stride + A.off[k];
         double* Bk = B.data + (long long)t * B.stride + B.off[k];
         // M (ra x rb) column-major: M[al + ra*be]

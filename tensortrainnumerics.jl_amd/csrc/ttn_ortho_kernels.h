@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(TTN_WG) k_orthogonalize(OrthoArgs P) {
     int which = 0;
     for (int j = 0; j < ic; ++j) {
         const int n = X.dims[j];
-        const int yl = (int)yr[j], rl = (int)xr[j], rr = (int)xr[j + 1];
+        const int yl = uni32((int)yr[j]), rl = uni32((int)xr[j]), rr = uni32((int)xr[j + 1]);
         double* Xj = X.data + (long long)b * X.stride + X.off[j];
         double* Yj = Y.data + (long long)b * Y.stride + Y.off[j];
         const int mm = yl * n;
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(TTN_WG) k_orthogonalize(OrthoArgs P) {
     int whichL = 0;
     for (int j = d - 1; j > ic; --j) {
         const int n = X.dims[j];
-        const int ynext = (int)yr[j + 1], rl = (int)xr[j], rr = (int)xr[j + 1];
+        const int ynext = uni32((int)yr[j + 1]), rl = uni32((int)xr[j]), rr = uni32((int)xr[j + 1]);
         double* Xj = X.data + (long long)b * X.stride + X.off[j];
         double* Yj = Y.data + (long long)b * Y.stride + Y.off[j];
         const int mm = ynext * n;
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(TTN_WG) k_orthogonalize(OrthoArgs P) {
     // ---- centre core: Y_i[s] = FR * X_i[s] * FL  (src/tt_tools.jl:537-541) ----
     {
         const int n = X.dims[ic];
-        const int yl = (int)yr[ic], yn = (int)yr[ic + 1], rl = (int)xr[ic], rr = (int)xr[ic + 1];
+        const int yl = uni32((int)yr[ic]), yn = uni32((int)yr[ic + 1]), rl = uni32((int)xr[ic]), rr = uni32((int)xr[ic + 1]);
         double* Xi = X.data + (long long)b * X.stride + X.off[ic];
         double* Yi = Y.data + (long long)b * Y.stride + Y.off[ic];
         const int mm = yl * n;
