@@ -735,9 +735,15 @@ __device__ inline double grp_from_next(double v) { return dpp_mov_f64<0x12C>(v);
 // Control flow: which waves work is wave-uniform (branches); which lane groups of a working wave hold real columns
 // (only the last block of a p not divisible by 4 has phantom columns) is a MASK — phantom groups load whatever the
 // LDS holds, their dot product is discarded and they never write — so that grp_sum / grp_from_next run converged.
-template <int NT2>
+// LD = leading dimension of the LDS image (128: up to 128 columns of <= 128 rows; 256: up to 64 columns of <= 256 rows, the
+// blocked driver below).  max_sweeps / cross_only / aneg_fixed serve that driver: one sweep per visit, optionally only the
+// TOP tournament level (= exactly the cross pairs between the first and the second half of the columns), and the
+// negligible-column threshold of the WHOLE matrix instead of the one of the columns at hand (aneg_fixed < 0: compute it).
+template <int NT2, int LD>
 __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* flag, double* red,
-                                  double tol_mult, double neg_mult, double* aneg_out) {
+                                  double tol_mult, double neg_mult, double* aneg_out, int max_sweeps = JACOBI_MAX_SWEEPS,
+                                  bool cross_only = false, double aneg_fixed = -1.0) {
+    constexpr int CMASK = (128 * 128) / LD - 1;         // columns the LDS image holds, minus one
     constexpr int G = 4;                                // lane groups per wave = columns per block
     constexpr int CH = 32;                              // doubles per 16-byte-per-lane piece of a column
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
@@ -749,15 +755,15 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
     const double tol2 = tol * tol;
     double aneg = 0.0;
     int sweep = 0;
-    for (; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+    for (; sweep < max_sweeps; ++sweep) {
         // ---- refresh the cached squared norms ----
         double amax = 0.0;
         for (int cb = wave * G; cb < p; cb += nwaves * G) {
-            const int c = cb + grp;                      // < 128: inside the LDS image even when >= p
+            const int c = (cb + grp) & CMASK;            // inside the LDS image even when >= p
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
             for (int t = 0; t < NT2; ++t) {
-                const lds_f64x2 v = *(lds_v2*)(X + c * 128 + JOFF(t));
+                const lds_f64x2 v = *(lds_v2*)(X + c * LD + JOFF(t));
                 a0 = fma(v.x, v.x, a0);
                 a1 = fma(v.y, v.y, a1);
             }
@@ -768,9 +774,12 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
             }
         }
         if (sweep == 0) {
-            amax = wg_max(amax, red);
-            aneg = neg_mult * neg_mult * (double)m * DBL_EPSILON * DBL_EPSILON * amax;
-            if (tid == 0) *aneg_out = aneg;
+            if (aneg_fixed >= 0.0) aneg = aneg_fixed;
+            else {
+                amax = wg_max(amax, red);
+                aneg = neg_mult * neg_mult * (double)m * DBL_EPSILON * DBL_EPSILON * amax;
+                if (tid == 0) *aneg_out = aneg;
+            }
         }
         if (tid == 0) *flag = 0;
         __syncthreads();
@@ -796,6 +805,7 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
                 const double cs = fast_rsqrt2(w_);                                                            \
                 const double sn = cs * t_;
         // ---- phase 0: pairs inside the blocks 2*slot and 2*slot+1 (circle method: local column 3 stays put) ----
+        if (!cross_only)
         for (int slot0 = wave; 2 * slot0 < nb; slot0 += nwaves) {
             const int blk = 2 * slot0 + (grp >> 1), hq = grp & 1;
             const int c0 = G * blk;
@@ -803,10 +813,10 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
             for (int rr = 0; rr < G - 1; ++rr) {
                 const int li = (hq == 0) ? G - 1 : (rr + hq) % (G - 1);
                 const int lj = (hq == 0) ? rr : (rr + G - 1 - hq) % (G - 1);
-                const int i = (c0 + (li < lj ? li : lj)) & 127, j = (c0 + (li < lj ? lj : li)) & 127;
+                const int i = (c0 + (li < lj ? li : lj)) & CMASK, j = (c0 + (li < lj ? lj : li)) & CMASK;
                 const bool act = j < p && blk < nb;
-                lds_f64* xi = X + i * 128;
-                lds_f64* xj = X + j * 128;
+                lds_f64* xi = X + i * LD;
+                lds_f64* xj = X + j * LD;
                 const double a = nrm2[i], b = nrm2[j];
                 lds_f64x2 u[NT2], v[NT2];
                 double g0 = 0.0, g1 = 0.0;
@@ -839,7 +849,7 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
         __syncthreads();
         // ---- levels ----
         constexpr int PPW = (16 + TTN_NWAVES - 1) / TTN_NWAVES;         // block pairs a wave owns per block round (p <= 128)
-        for (int gs = nbp; gs >= 2; gs >>= 1) {
+        for (int gs = nbp; gs >= (cross_only ? nbp : 2); gs >>= 1) {
             const int h = gs >> 1;
             int gam[PPW], aa[PPW], ci[PPW];
             bool wact[PPW], iact[PPW];
@@ -851,11 +861,11 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
                 wact[q] = slot < (nbp >> 1);                                // wave-uniform
                 gam[q] = wact[q] ? slot / h : 0;
                 aa[q] = wact[q] ? slot % h : 0;
-                ci[q] = (G * (gam[q] * gs + aa[q]) + grp) & 127;            // stationary column of this lane group
+                ci[q] = (G * (gam[q] * gs + aa[q]) + grp) & CMASK;            // stationary column of this lane group
                 iact[q] = wact[q] && ci[q] < p;
                 an[q] = nrm2[ci[q]];
 #pragma unroll
-                for (int t = 0; t < NT2; ++t) u[q][t] = *(lds_v2*)(X + ci[q] * 128 + JOFF(t));
+                for (int t = 0; t < NT2; ++t) u[q][t] = *(lds_v2*)(X + ci[q] * LD + JOFF(t));
             }
             for (int r = 0; r < h; ++r) {
 #pragma unroll
@@ -864,15 +874,15 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
                         int mrot = aa[q] + r; if (mrot >= h) mrot -= h;
                         const int cjb = G * (gam[q] * gs + h + mrot);
                         // the moving column this lane group starts with; it then takes the next group's column each inner round
-                        const int cj0 = (cjb + grp) & 127;
+                        const int cj0 = (cjb + grp) & CMASK;
                         lds_f64x2 v[NT2];
 #pragma unroll
-                        for (int t = 0; t < NT2; ++t) v[t] = *(lds_v2*)(X + cj0 * 128 + JOFF(t));
+                        for (int t = 0; t < NT2; ++t) v[t] = *(lds_v2*)(X + cj0 * LD + JOFF(t));
                         double b = nrm2[cj0];
                         int dirty = 0;
 #pragma unroll
                         for (int sft = 0; sft < G; ++sft) {
-                            const int cj = (cjb + ((grp + sft) & (G - 1))) & 127;
+                            const int cj = (cjb + ((grp + sft) & (G - 1))) & CMASK;
                             const bool act = iact[q] && cj < p;
                             double g0 = 0.0, g1 = 0.0;
 #pragma unroll
@@ -904,10 +914,10 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
                                 dirty = __builtin_amdgcn_update_dpp(0, dirty, 0x12C, 0xF, 0xF, true);
                             }
                         }
-                        const int cjl = (cjb + ((grp + G - 1) & (G - 1))) & 127;     // the column this group ends up with
+                        const int cjl = (cjb + ((grp + G - 1) & (G - 1))) & CMASK;     // the column this group ends up with
                         if (dirty && cjl < p) {
 #pragma unroll
-                            for (int t = 0; t < NT2; ++t) *(lds_v2*)(X + cjl * 128 + JOFF(t)) = v[t];
+                            for (int t = 0; t < NT2; ++t) *(lds_v2*)(X + cjl * LD + JOFF(t)) = v[t];
                             if (sub == 0) nrm2[cjl] = b;
                             rotated = 1;
                         }
@@ -919,7 +929,7 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
             for (int q = 0; q < PPW; ++q) {
                 if (iact[q]) {
 #pragma unroll
-                    for (int t = 0; t < NT2; ++t) *(lds_v2*)(X + ci[q] * 128 + JOFF(t)) = u[q][t];
+                    for (int t = 0; t < NT2; ++t) *(lds_v2*)(X + ci[q] * LD + JOFF(t)) = u[q][t];
                     if (sub == 0) nrm2[ci[q]] = an[q];
                 }
             }
@@ -943,9 +953,84 @@ __device__ TTN_NI_JACOBI int wg_jacobi_lds128(int m, int p, double* Xg, double* 
     if (p < 2) { if (threadIdx.x == 0) *aneg_out = 0.0; __syncthreads(); return 0; }
     lds_f64* X = (lds_f64*)Xg;
     lds_f64* nrm2 = (lds_f64*)nrm2g;
-    if (m <= 32) return jacobi_lds128_body<1>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
-    if (m <= 64) return jacobi_lds128_body<2>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
-    return jacobi_lds128_body<4>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
+    if (m <= 32) return jacobi_lds128_body<1, 128>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
+    if (m <= 64) return jacobi_lds128_body<2, 128>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
+    return jacobi_lds128_body<4, 128>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Blocked one-sided Jacobi for 128 < p <= 256 columns of length m <= 256 (ranks 65..128): the matrix (p x p doubles, up
+// to 512 KB) lives in global memory (column-major, leading dimension ldx) and is processed in column blocks of 32 through
+// the LDS image (leading dimension 256, 64 columns) by the same lane-group kernel as the p <= 128 fast path:
+//   per sweep   (a) every block alone: one full sweep over its 496 pairs;
+//               (b) every pair of blocks (I < J): I in columns 0..31, J in 32..63, only the top tournament level =
+//                   exactly the 32 x 32 cross pairs —
+//   i.e. every pair of columns once per sweep, like the cyclic orderings.  A block visit reads and writes its columns once
+//   (coalesced); a visit that rotated nothing is not written back.  Converged when a whole sweep rotates nothing.
+// Replaces the global-memory Jacobi (wg_jacobi_cols, 3-4x slower at these sizes), which remains the fallback for p > 256.
+// -------------------------------------------------------------------------------------------------
+#define JB_W 32
+__device__ inline void jb_load(lds_f64* X, int col0_lds, const double* Xg, int ldx, int c0, int ncols, int m) {
+    // columns c0 .. c0+ncols-1 of Xg -> LDS columns col0_lds .., rows >= m and missing columns zero-filled (32 columns always)
+    for (int e = threadIdx.x; e < JB_W * 256; e += TTN_WG) {
+        const int r = e & 255, c = e >> 8;
+        X[(col0_lds + c) * 256 + r] = (c < ncols && r < m) ? Xg[(long long)(c0 + c) * ldx + r] : 0.0;
+    }
+}
+__device__ inline void jb_store(const lds_f64* X, int col0_lds, double* Xg, int ldx, int c0, int ncols, int m) {
+    for (int e = threadIdx.x; e < JB_W * 256; e += TTN_WG) {
+        const int r = e & 255, c = e >> 8;
+        if (c < ncols && r < m) Xg[(long long)(c0 + c) * ldx + r] = X[(col0_lds + c) * 256 + r];
+    }
+}
+
+__device__ __noinline__ int wg_jacobi_blocked256(int m, int p, double* Xg, int ldx, double* Xlds, double* nrm2g, int* flag, double* red,
+                                                 double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
+    m = uni32(m); p = uni32(p); ldx = uni32(ldx);
+    Xg = unip(Xg); Xlds = unip(Xlds); nrm2g = unip(nrm2g); flag = unip(flag); red = unip(red); aneg_out = unip(aneg_out);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    lds_f64* X = (lds_f64*)Xlds;
+    lds_f64* nrm2 = (lds_f64*)nrm2g;
+    // negligible-column threshold of the whole matrix
+    double amax = 0.0;
+    for (int c = wave; c < p; c += nwaves) {
+        double a = 0.0;
+        for (int r = lane; r < m; r += 64) { const double v = Xg[(long long)c * ldx + r]; a = fma(v, v, a); }
+        amax = fmax(amax, wave_sum(a));
+    }
+    amax = wg_max(amax, red);
+    const double aneg = neg_mult * neg_mult * (double)m * DBL_EPSILON * DBL_EPSILON * amax;
+    if (tid == 0) *aneg_out = aneg;
+    __syncthreads();
+    const int nbk = (p + JB_W - 1) / JB_W;
+    for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+        int any = 0;
+        for (int I = 0; I < nbk; ++I) {                                           // (a) inside every block
+            const int nI = min(JB_W, p - I * JB_W);
+            __syncthreads();
+            jb_load(X, 0, Xg, ldx, I * JB_W, nI, m);
+            __syncthreads();
+            const int r = jacobi_lds128_body<8, 256>(m, nI, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out, 1, false, aneg);
+            if (r < 0) { any = 1; jb_store(X, 0, Xg, ldx, I * JB_W, nI, m); }
+        }
+        for (int I = 0; I + 1 < nbk; ++I)                                          // (b) between every two blocks
+            for (int J = I + 1; J < nbk; ++J) {
+                const int nJ = min(JB_W, p - J * JB_W);
+                __syncthreads();
+                jb_load(X, 0, Xg, ldx, I * JB_W, JB_W, m);
+                jb_load(X, JB_W, Xg, ldx, J * JB_W, nJ, m);
+                __syncthreads();
+                const int r = jacobi_lds128_body<8, 256>(m, JB_W + nJ, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out, 1, true, aneg);
+                if (r < 0) {
+                    any = 1;
+                    jb_store(X, 0, Xg, ldx, I * JB_W, JB_W, m);
+                    jb_store(X, JB_W, Xg, ldx, J * JB_W, nJ, m);
+                }
+            }
+        __syncthreads();
+        if (!any) return sweep + 1;
+    }
+    return -JACOBI_MAX_SWEEPS;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1109,7 +1194,8 @@ struct BondCtx {
 __device__ int wg_svd_cols(const CompressArgs& P, const BondCtx& S, int pj, double* X, int ldx, bool in_lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
     const int nsw = in_lds ? wg_jacobi_lds128(pj, pj, X, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
-                           : wg_jacobi_cols(pj, pj, X, ldx, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal);
+                  : (pj <= 256) ? wg_jacobi_blocked256(pj, pj, X, ldx, S.ldsX, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
+                                : wg_jacobi_cols(pj, pj, X, ldx, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal);
     for (int c = wave; c < pj; c += nwaves) {
         double a = 0.0;
         for (int r = lane; r < pj; r += 64) { const double v = X[(long long)c * ldx + r]; a = fma(v, v, a); }

@@ -466,6 +466,27 @@ def test_compress_short_side_above_128_uses_fallback(T):
     assert max(got.ttv_rks) == 100
 
 
+@pytest.mark.parametrize("d,r,mb", [(14, 100, 100), (16, 128, 128)])
+def test_compress_ranks_up_to_128_blocked_jacobi(T, d, r, mb):
+    """Merged short side 128 < p <= 256 (ranks 65..128): Householder LQ + the blocked LDS Jacobi (column blocks of 32 of a
+    matrix that lives in global memory).  Ranks exact, singular values 1e-10, tensor 1e-9 against the oracle."""
+    x = T.rand_tt((2,) * d, r, seed=4)
+    A = T.Delta(d)
+    dA, dx = T.DeviceTTO(A), T.DeviceTT.from_host(x)
+    dy = T.DeviceTT(x.ttv_dims, [a * b for a, b in zip(A.tto_rks, x.ttv_rks)])
+    dy.capture_singular_values(True)
+    T.device.apply_compress(dA, dx, dy, mb)
+    T.device.compress_status(dy)
+    got = dy.download()
+    sv = []
+    ref = O.tt_compress_(O.apply(O.Delta(d), to_oracle(x)), mb, svals_out=sv)
+    assert got.ttv_rks == ref.ttv_rks and max(got.ttv_rks) > 64
+    for i, s_ref in enumerate(sv):
+        s = dy.singular_values(0, i)
+        assert np.allclose(s[: len(s_ref)], s_ref, rtol=1e-10, atol=1e-13 * s_ref[0]), f"bond step {i}"
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
+
+
 def test_compress_truncerr_on_incompressible_input(T):
     d = 10
     x = T.Delta(d) * T.rand_tt((2,) * d, 8, seed=5)
