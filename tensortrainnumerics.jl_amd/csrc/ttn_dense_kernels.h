@@ -1551,6 +1551,10 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
                 ok = wg_chol_lds128(p, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
                 // with truncerr > 0 the rank rule reads the SMALL singular values too: need cond(M) <= kappa_max overall
                 if (ok && P.truncerr > 0.0 && S.scal[1] > FAST_KAPPA_MAX * FAST_KAPPA_MAX) ok = false;
+                // likewise when nothing will be truncated (p <= max_bond: every singular value is kept): the pivot ratio is a lower
+                // bound of cond(M)^2, so a value above the limit means the a-posteriori test WILL fail — go to Householder now
+                // instead of after a wasted Jacobi (the rank-ramp steps of a sweep are such steps)
+                if (ok && (long long)p <= P.max_bond && S.scal[1] > FAST_KAPPA_MAX * FAST_KAPPA_MAX) ok = false;
                 for (int e = tid; e < p * 128; e += TTN_WG) if ((e & 127) >= p) S.ldsX[e] = 0.0;      // zero row padding for the Jacobi
                 __syncthreads();
                 PROF_MARK(11)
