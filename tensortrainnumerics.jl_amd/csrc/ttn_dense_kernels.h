@@ -501,6 +501,47 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
     lds_gemm = unip(lds_gemm); Ts = unip(Ts); Ss = unip(Ss); taus = unip(taus); red = unip(red);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
     const int rr = min(p, q);
+#ifndef TTN_NO_LDS_LQ
+    if (!Qout && (long long)p * q <= GEMM_LDS_DOUBLES && rr <= 128) {
+        // ---- whole matrix in LDS (the small H-route steps of a sweep: 96x128, 64x128, ...): ONE "panel", no trailing
+        //      GEMMs at all — p reflectors, one barrier each, wave w applies H_r to rows r+1+w, r+1+w+16, ... ----
+        double* A = lds_gemm;
+        for (int e = tid; e < p * q; e += TTN_WG) A[e] = M2[(long long)(e / q) * ld + (e % q)];
+        __syncthreads();
+        for (int r = 0; r < rr; ++r) {
+            const double* row = A + (long long)r * q;
+            double s = 0.0;
+            for (int c = r + 1 + lane; c < q; c += 64) { const double v = row[c]; s = fma(v, v, s); }
+            const double xnorm2 = wave64_sum_fast(s);
+            const double alpha = row[r];
+            double tau = 0.0, scal = 0.0, beta = alpha;
+            if (xnorm2 > 0.0) {
+                beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha);
+                tau = (beta - alpha) / beta;
+                scal = 1.0 / (alpha - beta);
+            }
+            if (tid == 0) Ss[r] = beta;                      // Ss: 256 doubles, rr <= 128
+            for (int i = r + 1 + wave; tau != 0.0 && i < p; i += nwaves) {
+                double* ri = A + (long long)i * q;
+                double w = 0.0;
+                for (int c = r + 1 + lane; c < q; c += 64) w = fma(ri[c], row[c], w);
+                w = fma(scal, wave64_sum_fast(w), ri[r]);
+                const double tws = tau * w * scal;
+                for (int c = r + 1 + lane; c < q; c += 64) ri[c] = fma(-tws, row[c], ri[c]);
+                if (lane == 0) ri[r] -= tau * w;
+            }
+            __syncthreads();
+        }
+        // L (lower triangle, beta on the diagonal); the reflectors are not needed by the caller, the strict upper part is
+        // left as it is in M2 (callers read c <= r only)
+        for (int e = tid; e < p * rr; e += TTN_WG) {
+            const int r = e / rr, c = e % rr;
+            if (c <= r) M2[(long long)r * ld + c] = (c == r && r < rr) ? Ss[r] : A[(long long)r * q + c];
+        }
+        __syncthreads();
+        return;
+    }
+#endif
     double* betas = Ss;                                  // QR_NB (Ss is free while a panel is being factored)
     double* scl = Ss + QR_NB;                            // QR_NB
     for (int j0 = 0; j0 < rr; j0 += QR_NB) {

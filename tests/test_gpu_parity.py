@@ -469,7 +469,10 @@ def test_compress_short_side_above_128_uses_fallback(T):
 @pytest.mark.parametrize("d,r,mb", [(14, 100, 100), (16, 128, 128)])
 def test_compress_ranks_up_to_128_blocked_jacobi(T, d, r, mb):
     """Merged short side 128 < p <= 256 (ranks 65..128): Householder LQ + the blocked LDS Jacobi (column blocks of 32 of a
-    matrix that lives in global memory).  Ranks exact, singular values 1e-10, tensor 1e-9 against the oracle."""
+    matrix that lives in global memory).  Ranks exact, tensor 1e-9 against the oracle; per-bond singular values rtol 1e-10
+    with atol 1e-12*sigma_1: at these sizes (256 x 512 merged matrices, 30 un-gauged steps each feeding the next) device and
+    LAPACK trajectories drift apart by a few 1e-13*sigma_1 (measured 2e-13..7e-13, tests/diag_sv_err.py), the same size for the
+    blocked and the in-LDS Householder — the 1e-13 of the rank-64 tests is too tight here."""
     x = T.rand_tt((2,) * d, r, seed=4)
     A = T.Delta(d)
     dA, dx = T.DeviceTTO(A), T.DeviceTT.from_host(x)
@@ -483,7 +486,7 @@ def test_compress_ranks_up_to_128_blocked_jacobi(T, d, r, mb):
     assert got.ttv_rks == ref.ttv_rks and max(got.ttv_rks) > 64
     for i, s_ref in enumerate(sv):
         s = dy.singular_values(0, i)
-        assert np.allclose(s[: len(s_ref)], s_ref, rtol=1e-10, atol=1e-13 * s_ref[0]), f"bond step {i}"
+        assert np.allclose(s[: len(s_ref)], s_ref, rtol=1e-10, atol=1e-12 * s_ref[0]), f"bond step {i}"
     assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
 
 
