@@ -1581,7 +1581,10 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
         double* X = x_in_lds ? S.ldsX : S.Xg;
         const int ldx = x_in_lds ? 128 : p;
 
-        for (int attempt = (P.fast && need_lq && x_in_lds && p >= 2) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
+        // small merged matrices (the rank-ramp steps) fit the LDS whole: their Householder LQ needs no GEMM calls and costs
+        // about what the Gram + Cholesky do, without the conditioning gamble — route H directly
+        const bool lq_in_lds = (long long)p * q <= GEMM_LDS_DOUBLES;
+        for (int attempt = (P.fast && need_lq && x_in_lds && p >= 2 && !lq_in_lds) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
             bool ok = true;
             if (attempt == 1) {
                 // =========================== route G: L = chol(M M^T) ===========================
