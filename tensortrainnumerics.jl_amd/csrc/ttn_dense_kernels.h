@@ -98,6 +98,7 @@ struct GemmDesc {
 #define GEMM_DESC_DOUBLES (32 + GEMM_TAB_ENTRIES)
 #define GEMM_LDS_TOTAL (GEMM_LDS_DOUBLES + GEMM_DESC_DOUBLES)
 typedef __attribute__((address_space(3))) long long lds_i64;
+typedef __attribute__((address_space(3))) int lds_i32;
 // GEMM A/B operands always live in global memory.  Loading them through the generic `double*` of a View makes the
 // compiler emit flat_load, which counts on lgkmcnt as well as vmcnt — every `s_waitcnt lgkmcnt(0)` in front of an MFMA
 // group (meant for the LDS fragment reads) then also waits for the global loads of the NEXT chunk: measured 49 % -> 7x %
@@ -145,8 +146,9 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
     const int li = lane & 15, lk = lane >> 4;
     gmem_f64* Ag = (gmem_f64*)A.p;
     gmem_f64* Bg = (gmem_f64*)B.p;
-    lds_i64* tabA = (lds_i64*)(lds + GEMM_LDS_DOUBLES + 32);      // ix(A.c, slab0 + j), j < GEMM_KSLAB
-    lds_i64* tabB = tabA + GEMM_KSLAB;                            // ix(B.r, slab0 + j)
+    // element offsets fit 32 bits (operands are at most 4096 x 16384 doubles): half the registers of 64-bit ones
+    lds_i32* tabA = (lds_i32*)(lds + GEMM_LDS_DOUBLES + 32);      // ix(A.c, slab0 + j), j < GEMM_KSLAB
+    lds_i32* tabB = tabA + GEMM_KSLAB;                            // ix(B.r, slab0 + j)
     const bool a_kfast = minstride(A.c) < minstride(A.r);
     const bool b_kfast = minstride(B.r) < minstride(B.c);
     // staging assignment: element e = tid + TTN_WG*u of the BM x BK (A) and BK x BN (B) chunk
@@ -167,12 +169,12 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
     int slab0 = -1;                                               // first k index the tables currently hold
     for (int m0 = 0; m0 < m; m0 += BM) {
         for (int n0 = 0; n0 < n; n0 += BN) {
-            long long aoff[NUA], boff[NUB];
+            int aoff[NUA], boff[NUB];
             bool aok[NUA], bok[NUB];
 #pragma unroll
-            for (int u = 0; u < NUA; ++u) { aok[u] = (m0 + ar[u]) < m; aoff[u] = aok[u] ? ix(A.r, m0 + ar[u]) : 0; }
+            for (int u = 0; u < NUA; ++u) { aok[u] = (m0 + ar[u]) < m; aoff[u] = aok[u] ? (int)ix(A.r, m0 + ar[u]) : 0; }
 #pragma unroll
-            for (int u = 0; u < NUB; ++u) { bok[u] = (n0 + bc[u]) < n; boff[u] = bok[u] ? ix(B.c, n0 + bc[u]) : 0; }
+            for (int u = 0; u < NUB; ++u) { bok[u] = (n0 + bc[u]) < n; boff[u] = bok[u] ? (int)ix(B.c, n0 + bc[u]) : 0; }
             const bool live = (m0 + wr * 32 < m) && (n0 + wc * 32 < n);      // wave-uniform
             mfma_acc_t acc[2][2];
 #pragma unroll
@@ -188,14 +190,14 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
                 slab0 = (K0);                                                                                   \
                 for (int j = tid; j < GEMM_KSLAB; j += TTN_WG) {                                                \
                     const int kk = slab0 + j;                                                                   \
-                    tabA[j] = (kk < k) ? ix(A.c, kk) : 0;                                                       \
-                    tabB[j] = (kk < k) ? ix(B.r, kk) : 0;                                                       \
+                    tabA[j] = (kk < k) ? (int)ix(A.c, kk) : 0;                                                     \
+                    tabB[j] = (kk < k) ? (int)ix(B.r, kk) : 0;                                                     \
                 }                                                                                               \
                 __syncthreads();                                                                                \
             }
 #define GEMM_LOAD(K0)  /* branch-free: out-of-range elements read element 0 of the operand and are then zeroed */        \
             {                                                                                                   \
-                long long oa_[NUA], ob_[NUB];                                                                   \
+                int oa_[NUA], ob_[NUB];                                                                         \
                 bool va_[NUA], vb_[NUB];                                                                        \
                 _Pragma("unroll") for (int u = 0; u < NUA; ++u) {                                               \
                     const int ga = (K0) + akk[u];                                                               \
