@@ -223,11 +223,16 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
             }
             if (slab0 != 0) GEMM_FILL_TAB(0)
             else __syncthreads();                      // the previous tile's MFMAs have consumed both stages
-            GEMM_LOAD(0)
-            GEMM_STORE(0)
-            if (nch > 1) {
-                if (GEMM_BK >= slab0 + GEMM_KSLAB) GEMM_FILL_TAB(GEMM_BK)
-                GEMM_LOAD(GEMM_BK)
+            {   // prologue: the loads of chunk 0 AND chunk 1 are in flight together (one exposed global latency, not two)
+                GEMM_LOAD(0)
+                double av0[NUA], bv0[NUB];
+                _Pragma("unroll") for (int u = 0; u < NUA; ++u) av0[u] = av[u];
+                _Pragma("unroll") for (int u = 0; u < NUB; ++u) bv0[u] = bv[u];
+                if (nch > 1) GEMM_LOAD(GEMM_BK)
+                lds_f64* As0 = (lds_f64*)lds;
+                lds_f64* Bs0 = As0 + GEMM_BK * LDA;
+                _Pragma("unroll") for (int u = 0; u < NUA; ++u) As0[akk[u] * LDA + ar[u]] = av0[u];
+                _Pragma("unroll") for (int u = 0; u < NUB; ++u) Bs0[bkk[u] * LDB + bc[u]] = bv0[u];
             }
             __syncthreads();
             for (int c = 0; c < nch; ++c) {
@@ -262,19 +267,27 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
 #undef GEMM_FILL_TAB
 #undef GEMM_LOAD
 #undef GEMM_STORE
+            // C offsets of this tile through tables too (ten ix() per thread otherwise: two integer divisions each)
+            lds_i32* rowC = tabB + GEMM_KSLAB;                            // BM entries
+            lds_i32* colC = rowC + BM;                                    // BN entries
+            for (int i = tid; i < BM + BN; i += TTN_WG) {
+                if (i < BM) rowC[i] = (m0 + i < m) ? (int)ix(C.r, m0 + i) : 0;
+                else colC[i - BM] = (n0 + i - BM < n) ? (int)ix(C.c, n0 + i - BM) : 0;
+            }
+            __syncthreads();
             if (live) {
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const int gi = m0 + wr * 32 + ti * 16 + lk + 4 * reg;
-                        if (gi >= m) continue;
-                        const long long ro = ix(C.r, gi);
+                        const int li_ = wr * 32 + ti * 16 + lk + 4 * reg;
+                        if (m0 + li_ >= m) continue;
+                        const int ro = rowC[li_];
 #pragma unroll
                         for (int tj = 0; tj < 2; ++tj) {
-                            const int gj = n0 + wc * 32 + tj * 16 + li;
-                            if (gj >= n) continue;
-                            double* cp = C.p + ro + ix(C.c, gj);
+                            const int lj_ = wc * 32 + tj * 16 + li;
+                            if (n0 + lj_ >= n) continue;
+                            double* cp = C.p + ((long long)ro + colC[lj_]);
                             double v = alpha * acc[ti][tj][reg];
                             if (beta != 0.0) v += beta * (*cp);
                             *cp = v;
