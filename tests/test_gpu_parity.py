@@ -575,6 +575,44 @@ def test_fused_apply_compress_equals_apply_then_compress(T, monkeypatch, dims, o
             assert u.ttv_rks == ref.ttv_rks and tt_rel_diff(to_oracle(u), ref) <= 1e-9
 
 
+def test_sweep_ranges_and_core_handoff_reproduce_compress(T):
+    """ttn_sweep over 1..d-1 then d-1..1 is tt_compress! (same bond steps, same order: identical cores); cutting the chain at
+    a bond and moving the boundary core through ttn_tt_core_export / _import (what pipeline.py sends over RCCL) too."""
+    import ctypes as C
+    import torch
+    d, r, B = 12, 16, 3
+    A = T.Delta(d)
+    x = T.rand_tt((2,) * d, r, seed=9)
+    dA, dx = T.DeviceTTO(A), T.DeviceTT.from_host(x, batch=B)
+    cap = [a * c for a, c in zip(A.tto_rks, x.ttv_rks)]
+    ref, two = T.DeviceTT((2,) * d, cap, batch=B), T.DeviceTT((2,) * d, cap, batch=B)
+    T.device.apply(dA, dx, ref); T.device.tt_compress_(ref, r)
+    T.device.apply(dA, dx, two)
+    L = T._lib.lib()
+    T._lib.check(L.ttn_sweep(two.h, 1, d - 1, r, 0.0))
+    # round trip of core 5 through a dense device buffer between the two sweep directions
+    n, bl, br = C.c_int64(), C.c_int64(), C.c_int64()
+    T._lib.check(L.ttn_tt_core_extent(two.h, 5, C.byref(n), C.byref(bl), C.byref(br)))
+    buf = torch.empty((B, n.value), dtype=torch.float64, device="cuda")
+    rk2 = torch.empty((B, 2), dtype=torch.int64, device="cuda")
+    T._lib.check(L.ttn_tt_core_export(two.h, 5, buf.data_ptr(), rk2.data_ptr()))
+    T.device.sync()
+    assert rk2.cpu().tolist() == [[int(bl.value), int(br.value)]] * B or all(a <= bl.value and c <= br.value for a, c in rk2.cpu().tolist())
+    T._lib.check(L.ttn_tt_core_import(two.h, 5, buf.data_ptr(), rk2.data_ptr(), bl.value, br.value))
+    T._lib.check(L.ttn_sweep(two.h, d - 1, 1, r, 0.0))
+    T.device.sync()
+    for b in range(B):
+        a_, b_ = ref.download(b), two.download(b)
+        assert a_.ttv_rks == b_.ttv_rks
+        for k in range(d):
+            assert np.array_equal(a_.ttv_vec[k], b_.ttv_vec[k])
+    # argument checking: bond indices are 1-based in 1:(N-1); an import that does not fit the slot is refused
+    with pytest.raises(AssertionError):                      # like the reference's @assert 1 <= k < N (tt_tools.jl:744)
+        T._lib.check(L.ttn_sweep(two.h, 0, 3, r, 0.0))
+    with pytest.raises(T.TTNError):
+        T._lib.check(L.ttn_tt_core_import(two.h, 5, buf.data_ptr(), rk2.data_ptr(), 10 ** 6, 1))
+
+
 # ------------------------------------------------------------------------------------------------
 # device-resident caller chains (SURVEY §8 f3): rk4_method / euler_method of src/solvers/euler.jl on handles
 # ------------------------------------------------------------------------------------------------
