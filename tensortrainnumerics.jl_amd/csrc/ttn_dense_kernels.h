@@ -1625,10 +1625,35 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
                     wg_lq_blocked(p, q, S.M2, q, S.Vb, S.Wb, nullptr, nullptr, lds, S.Ts, S.Ss, S.taus, S.red);
                 }
                 const double* Lsrc = need_lq ? S.M2 : S.M;               // row-major, ld = q
+#ifndef TTN_NO_PRESORT
+                // columns of L in order of decreasing norm (de Rijk): the rank-deficient L of the ramp steps converges in
+                // fewer sweeps that way; any column order is fine for the caller (wg_svd_cols sorts by sigma anyway)
+                if (need_lq && x_in_lds) {
+                    const int lane_ = tid & 63, wave_ = tid >> 6;
+                    for (int c = wave_; c < p; c += TTN_NWAVES) {
+                        double a = 0.0;
+                        for (int r_ = c + lane_; r_ < p; r_ += 64) { const double v = Lsrc[(long long)r_ * q + c]; a = fma(v, v, a); }
+                        a = wave_sum(a);
+                        if (lane_ == 0) S.sig[c] = a;
+                    }
+                    __syncthreads();
+                    for (int c = tid; c < p; c += TTN_WG) {
+                        const double sc = S.sig[c];
+                        int pos = 0;
+                        for (int j = 0; j < p; ++j) { const double sj = S.sig[j]; pos += (sj > sc) || (sj == sc && j < c); }
+                        S.perm[c] = pos;                                    // column c of L goes to position pos
+                    }
+                    __syncthreads();
+                }
+                const bool presort = need_lq && x_in_lds;
+#else
+                const bool presort = false;
+#endif
                 for (int e = tid; e < p * ldx; e += TTN_WG) {
                     const int r_ = e % ldx, c = e / ldx;              // X[r + ldx*c] = L[r][c]; rows >= p are zero padding
                     const double v = (r_ < p) ? Lsrc[(long long)r_ * q + c] * (need_lq ? 1.0 : inv_s0) : 0.0;
-                    X[(long long)c * ldx + r_] = (need_lq && c > r_) ? 0.0 : v;
+                    const int cd = presort ? S.perm[c] : c;
+                    X[(long long)cd * ldx + r_] = (need_lq && c > r_) ? 0.0 : v;
                 }
                 __syncthreads();
                 PROF_MARK(2)
@@ -1722,7 +1747,10 @@ __global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {
             k = (i < d - 1) ? i : per_sweep - 1 - i;
             virt = P.fused && step < d - 1;                                      // first L->R sweep of the fused op
         }
+        const long long ts_ = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
         wg_bond_step(P, b, k, step, lds, virt);
+        if (P.prof && step < 120 && threadIdx.x == 0)            // bits 12..31 of the step word: kilo-cycles of the step
+            P.prof[(long long)P.tt.batch * 16 + (long long)b * 120 + step] |= ((((long long)__builtin_amdgcn_s_memtime() - ts_) >> 10) & 0xFFFFF) << 12;
     }
 }
 
