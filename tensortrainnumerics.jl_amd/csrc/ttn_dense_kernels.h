@@ -508,6 +508,49 @@ __device__ inline double wave64_sum_fast(double v) {
     return t;
 }
 
+// Householder LQ of a p x qc matrix (row-major, leading dimension lds_) entirely in LDS: p reflectors, one barrier each,
+// wave w applies H_r to rows r+1+w, r+1+w+16, ...  Writes L (lower triangle, p x min(p,qc)) to dst (row-major, leading
+// dimension ldd); with `full` also zeros above the diagonal up to column p-1 (the L blocks of a TSQR level are read whole).
+// Ss: >= 128 doubles of LDS for the diagonal.  A: the LDS image (>= p*qc doubles).
+__device__ inline void lq_lds_whole(int p, int qc, const double* src, int lds_, double* dst, int ldd, double* A, double* Ss, bool full) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    const int rr = min(p, qc);
+    __syncthreads();
+    for (int e = tid; e < p * qc; e += TTN_WG) A[e] = src[(long long)(e / qc) * lds_ + (e % qc)];
+    __syncthreads();
+    for (int r = 0; r < rr; ++r) {
+        const double* row = A + (long long)r * qc;
+        double s = 0.0;
+        for (int c = r + 1 + lane; c < qc; c += 64) { const double v = row[c]; s = fma(v, v, s); }
+        const double xnorm2 = wave64_sum_fast(s);
+        const double alpha = row[r];
+        double tau = 0.0, scal = 0.0, beta = alpha;
+        if (xnorm2 > 0.0) {
+            beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha);
+            tau = (beta - alpha) / beta;
+            scal = 1.0 / (alpha - beta);
+        }
+        if (tid == 0) Ss[r] = beta;
+        for (int i = r + 1 + wave; tau != 0.0 && i < p; i += nwaves) {
+            double* ri = A + (long long)i * qc;
+            double w = 0.0;
+            for (int c = r + 1 + lane; c < qc; c += 64) w = fma(ri[c], row[c], w);
+            w = fma(scal, wave64_sum_fast(w), ri[r]);
+            const double tws = tau * w * scal;
+            for (int c = r + 1 + lane; c < qc; c += 64) ri[c] = fma(-tws, row[c], ri[c]);
+            if (lane == 0) ri[r] -= tau * w;
+        }
+        __syncthreads();
+    }
+    const int ncol = full ? p : rr;
+    for (int e = tid; e < p * ncol; e += TTN_WG) {
+        const int r = e / ncol, c = e % ncol;
+        if (c <= r && c < rr) dst[(long long)r * ldd + c] = (c == r) ? Ss[r] : A[(long long)r * qc + c];
+        else if (full) dst[(long long)r * ldd + c] = 0.0;
+    }
+    __syncthreads();
+}
+
 __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, double* Vb, double* Wb, double* Tst, double* Qout,
                                            double* lds_gemm, double* Ts, double* Ss, double* taus, double* red) {
     // arguments of an out-of-line function arrive in VGPRs: pin the workgroup-uniform ones to SGPRs
@@ -517,44 +560,25 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
     const int rr = min(p, q);
 #ifndef TTN_NO_LDS_LQ
-    if (!Qout && (long long)p * q <= GEMM_LDS_DOUBLES && rr <= 128) {
-        // ---- whole matrix in LDS (the small H-route steps of a sweep: 96x128, 64x128, ...): ONE "panel", no trailing
-        //      GEMMs at all — p reflectors, one barrier each, wave w applies H_r to rows r+1+w, r+1+w+16, ... ----
-        double* A = lds_gemm;
-        for (int e = tid; e < p * q; e += TTN_WG) A[e] = M2[(long long)(e / q) * ld + (e % q)];
-        __syncthreads();
-        for (int r = 0; r < rr; ++r) {
-            const double* row = A + (long long)r * q;
-            double s = 0.0;
-            for (int c = r + 1 + lane; c < q; c += 64) { const double v = row[c]; s = fma(v, v, s); }
-            const double xnorm2 = wave64_sum_fast(s);
-            const double alpha = row[r];
-            double tau = 0.0, scal = 0.0, beta = alpha;
-            if (xnorm2 > 0.0) {
-                beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha);
-                tau = (beta - alpha) / beta;
-                scal = 1.0 / (alpha - beta);
+    // ---- matrices that fit the LDS whole (the small H-route steps of a sweep: 96x128, 64x128, ...): ONE "panel", no
+    //      trailing GEMMs at all.  Wider ones with p <= 88 rows go through the LDS in column chunks of width w >= 2p
+    //      (TSQR): L_i of every chunk is written back side by side, [L_1 L_2 ...] is factored again until one chunk is left
+    //      — M M^T = sum L_i L_i^T, so the final L is an L factor of M (the callers use L only, never Q) ----
+    if (!Qout && rr == p && p <= 128) {
+        const int w = GEMM_LDS_DOUBLES / p;                // columns of a chunk
+        if (q <= w || w >= 2 * p) {
+            int qc = q;                                     // current width of the matrix held in M2[:, 0:qc]
+            for (;;) {
+                const int nchunk = (qc + w - 1) / w;
+                for (int ci = 0; ci < nchunk; ++ci) {
+                    const int c0 = ci * w, cw = min(w, qc - c0);
+                    lq_lds_whole(p, cw, M2 + c0, ld, M2 + (long long)ci * p, ld, lds_gemm, Ss, nchunk > 1);
+                }
+                if (nchunk == 1) break;
+                qc = nchunk * p;
             }
-            if (tid == 0) Ss[r] = beta;                      // Ss: 256 doubles, rr <= 128
-            for (int i = r + 1 + wave; tau != 0.0 && i < p; i += nwaves) {
-                double* ri = A + (long long)i * q;
-                double w = 0.0;
-                for (int c = r + 1 + lane; c < q; c += 64) w = fma(ri[c], row[c], w);
-                w = fma(scal, wave64_sum_fast(w), ri[r]);
-                const double tws = tau * w * scal;
-                for (int c = r + 1 + lane; c < q; c += 64) ri[c] = fma(-tws, row[c], ri[c]);
-                if (lane == 0) ri[r] -= tau * w;
-            }
-            __syncthreads();
+            return;
         }
-        // L (lower triangle, beta on the diagonal); the reflectors are not needed by the caller, the strict upper part is
-        // left as it is in M2 (callers read c <= r only)
-        for (int e = tid; e < p * rr; e += TTN_WG) {
-            const int r = e / rr, c = e % rr;
-            if (c <= r) M2[(long long)r * ld + c] = (c == r && r < rr) ? Ss[r] : A[(long long)r * q + c];
-        }
-        __syncthreads();
-        return;
     }
 #endif
     double* betas = Ss;                                  // QR_NB (Ss is free while a panel is being factored)
@@ -1598,7 +1622,7 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
 
         // small merged matrices (the rank-ramp steps) fit the LDS whole: their Householder LQ needs no GEMM calls and costs
         // about what the Gram + Cholesky do, without the conditioning gamble — route H directly
-        const bool lq_in_lds = (long long)p * q <= GEMM_LDS_DOUBLES;
+        const bool lq_in_lds = (long long)p * q <= GEMM_LDS_DOUBLES || GEMM_LDS_DOUBLES / p >= 2 * p;     // whole, or TSQR chunks (wg_lq_blocked)
         for (int attempt = (P.fast && need_lq && x_in_lds && p >= 2 && !lq_in_lds) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
             bool ok = true;
             if (attempt == 1) {
