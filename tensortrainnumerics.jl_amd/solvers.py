@@ -6,9 +6,12 @@ Mirrors of the explicit time steppers of the reference that are literally chains
     euler_method(A, u0, steps; normalize)          src/solvers/euler.jl:76-97
     rk4_method(A, u0, steps, max_bond; normalize)   src/solvers/euler.jl:193-209
 
-They run on ``DeviceTT`` batches (every train of the batch is an independent initial condition), never
-leave HBM between ops, and return a new ``DeviceTT``.  The ``return_error`` branches and the implicit
-steppers (which need ALS/DMRG/Krylov linear solves) are not built.
+    krylov_linsolve(A, b, guess; max_bond, krylov_solver, ...)       src/solvers/euler.jl:34-74
+    implicit_euler_method / crank_nicholson_method (tt_solver = "krylov")   src/solvers/euler.jl:98-190
+
+They run on ``DeviceTT`` batches (every train of the batch is an independent initial condition / linear system),
+never leave HBM between ops, and return a new ``DeviceTT``.  The ``return_error`` branches and the ALS/MALS/DMRG
+solvers of the implicit steppers are not built.
 """
 from __future__ import annotations
 
@@ -110,3 +113,284 @@ def euler_method(A: DeviceTTO, u0: DeviceTT, steps: Sequence[float], normalize: 
             u.free()
         u, ur, own = un, unr, True
     return u
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Krylov linear solves on handles: krylov_linsolve (src/solvers/euler.jl:34-74) and the implicit steppers
+# that call it (implicit_euler_method :98-140, crank_nicholson_method :142-190) with tt_solver = "krylov".
+#
+# The reference hands `op`, `b`, `guess` to KrylovKit.linsolve (BiCGStab / GMRES / CG) — a third-party package that is not
+# part of the reference tree (Project.toml compat 0.6.1, 0.9, 0.10), so its exact iteration (restart policy, breakdown
+# handling) cannot be restated: what is mirrored here is the reference's OWN part — the operator
+#     op = max_bond > 0 ? x -> tt_compress!(A*x, max_bond) : x -> A*x                              (euler.jl:55)
+# the tolerance tol = max(atol, rtol*norm(b)) (:57), the solver selection (:56, :9-32) and the vector algebra of the
+# VectorInterface extension (add = _round(beta*y + alpha*x) with _round = tt_compress!(., max_bond) during a bounded
+# solve, orthogonalize otherwise; ext/...VectorInterfaceExt.jl:11-51) — around the textbook forms of the three Krylov
+# methods.  Parity is therefore pinned where the reference's tests pin it: the solution against a dense solve
+# (test/test_euler.jl:105-240: 1e-8 / 1e-7) and the rank bound; iterates are "parity unpinned".
+# Every train of the batch is an independent system (same A, own right-hand side): scalars are per-train vectors.
+# ----------------------------------------------------------------------------------------------------------------------
+import numpy as np
+
+from .tt import TToperator
+
+
+def _tto_scale(a: float, A: TToperator) -> TToperator:
+    """a * A for operators: scales the first core (src/tt_operations.jl:268-281)."""
+    cores = [np.array(c, order="F") for c in A.tto_vec]
+    cores[0] = a * cores[0]
+    return TToperator(A.N, cores, A.tto_dims, list(A.tto_rks), list(A.tto_ot))
+
+
+def _tto_add(A: TToperator, B: TToperator) -> TToperator:
+    """A + B for operators: block concatenation of the cores (src/tt_operations.jl:71-96)."""
+    assert A.tto_dims == B.tto_dims, "Incompatible dimensions"
+    d = A.N
+    cores, rks = [], [1]
+    for k in range(d):
+        a, b = A.tto_vec[k], B.tto_vec[k]
+        n = a.shape[0]
+        ral, rar, rbl, rbr = a.shape[2], a.shape[3], b.shape[2], b.shape[3]
+        rl = 1 if k == 0 else ral + rbl
+        rr = 1 if k == d - 1 else rar + rbr
+        c = np.zeros((n, n, rl, rr), order="F")
+        if d == 1:
+            c[:] = a + b
+        elif k == 0:
+            c[:, :, 0, :rar] = a[:, :, 0, :]; c[:, :, 0, rar:] = b[:, :, 0, :]
+        elif k == d - 1:
+            c[:, :, :ral, 0] = a[:, :, :, 0]; c[:, :, ral:, 0] = b[:, :, :, 0]
+        else:
+            c[:, :, :ral, :rar] = a; c[:, :, ral:, rar:] = b
+        cores.append(c)
+        rks.append(rr)
+    return TToperator(d, cores, A.tto_dims, rks, [0] * d)
+
+
+class _Vec:
+    """A DeviceTT batch together with the host-side rank bound the capacity arithmetic needs."""
+
+    def __init__(self, h: DeviceTT, rks, own: bool = True):
+        self.h, self.rks, self.own = h, list(rks), own
+
+    def free(self):
+        if self.own and self.h is not None:
+            self.h.free()
+            self.h = None
+
+
+def _lin(a, x: _Vec, b, y: _Vec) -> _Vec:
+    """a .* x + b .* y with per-train scalars (b*y + a*x as the extension writes it: scalar * first, then +)."""
+    B = x.h.batch
+    ax, by = DeviceTT(x.h.dims, x.rks, B), DeviceTT(y.h.dims, y.rks, B)
+    D.scale_batch(np.broadcast_to(np.asarray(a, dtype=float), (B,)).copy(), x.h, ax)
+    D.scale_batch(np.broadcast_to(np.asarray(b, dtype=float), (B,)).copy(), y.h, by)
+    zr = [p + q for p, q in zip(x.rks, y.rks)]
+    zr[0] = zr[-1] = 1
+    z = DeviceTT(x.h.dims, zr, B)
+    D.add(by, ax, z)
+    ax.free(); by.free()
+    return _Vec(z, zr)
+
+
+def _copy(v: _Vec) -> _Vec:
+    from . import _lib
+    c = DeviceTT(v.h.dims, v.rks, v.h.batch)
+    _lib.check(_lib.lib().ttn_tt_copy(c.h, v.h.h))
+    return _Vec(c, v.rks)
+
+
+def _scale(v: _Vec, coef) -> _Vec:
+    """coef .* v (per-train scalars) into a fresh handle; same ranks, so nothing to round."""
+    c = DeviceTT(v.h.dims, v.rks, v.h.batch)
+    D.scale_batch(np.broadcast_to(np.asarray(coef, dtype=float), (v.h.batch,)).copy(), v.h, c)
+    return _Vec(c, v.rks)
+
+
+def _round(v: _Vec, round_rank: int) -> _Vec:
+    """VectorInterface ext `_round`: tt_compress!(r, rk) during a bounded Krylov solve, orthogonalize(r) otherwise."""
+    if round_rank > 0:
+        h, fin = _compress(v.h, v.rks, round_rank)
+        return _Vec(h, fin)
+    o = DeviceTT(v.h.dims, v.rks, v.h.batch)
+    D.orthogonalize(v.h, 1, o)
+    v.free()
+    return _Vec(o, _ranks_of(o))
+
+
+def _vi_add(y: _Vec, x: _Vec, alpha, beta, round_rank: int) -> _Vec:
+    """VectorInterface.add(y, x, alpha, beta) = _round(beta*y + alpha*x)."""
+    return _round(_lin(alpha, x, beta, y), round_rank)
+
+
+def _make_op(A: DeviceTTO, max_bond: int):
+    def op(x: _Vec) -> _Vec:
+        y, yr = _apply(A, x.h, x.rks)
+        if max_bond > 0:
+            y, yr = _compress(y, yr, max_bond)
+        return _Vec(y, yr)
+    return op
+
+
+def _safe_div(num, den):
+    num, den = np.asarray(num, dtype=float), np.asarray(den, dtype=float)
+    return np.where(den != 0.0, num / np.where(den != 0.0, den, 1.0), 0.0)
+
+
+def _bicgstab(op, b: _Vec, x: _Vec, tol, maxiter: int, rr: int) -> _Vec:
+    """van der Vorst's BiCGStab, per-train scalars; trains that have converged keep iterating with zero updates."""
+    Ax = op(x)
+    r = _vi_add(b, Ax, -1.0, 1.0, rr); Ax.free()
+    rhat = _Vec(r.h, r.rks, own=False)
+    rhat_keep = r                                             # r is replaced below; keep the shadow residual alive
+    r = _copy(rhat)
+    B = b.h.batch
+    rho = alpha = omega = np.ones(B)
+    v = p = None
+    for it in range(maxiter):
+        if np.all(D.norm(r.h) <= tol):
+            break
+        rho_new = D.dot(rhat.h, r.h)
+        if p is None:
+            p = _copy(r)
+        else:
+            beta = _safe_div(rho_new, rho) * _safe_div(alpha, omega)
+            t = _vi_add(p, v, -omega, 1.0, rr)                # p - omega v
+            pn = _vi_add(r, t, beta, 1.0, rr); t.free(); p.free(); p = pn
+        if v is not None:
+            v.free()
+        v = op(p)
+        alpha = _safe_div(rho_new, D.dot(rhat.h, v.h))
+        s = _vi_add(r, v, -alpha, 1.0, rr)
+        t = op(s)
+        tt_ = D.dot(t.h, t.h)
+        omega = _safe_div(D.dot(t.h, s.h), tt_)
+        xa = _vi_add(x, p, alpha, 1.0, rr); x.free()
+        x = _vi_add(xa, s, omega, 1.0, rr); xa.free()
+        rn = _vi_add(s, t, -omega, 1.0, rr); s.free(); t.free(); r.free(); r = rn
+        rho = rho_new
+    for w in (r, p, v, rhat_keep):
+        if w is not None:
+            w.free()
+    return x
+
+
+def _cg(op, b: _Vec, x: _Vec, tol, maxiter: int, rr: int) -> _Vec:
+    Ax = op(x)
+    r = _vi_add(b, Ax, -1.0, 1.0, rr); Ax.free()
+    p = _copy(r)
+    rs = D.dot(r.h, r.h)
+    for it in range(maxiter):
+        if np.all(np.sqrt(np.maximum(rs, 0.0)) <= tol):
+            break
+        Ap = op(p)
+        alpha = _safe_div(rs, D.dot(p.h, Ap.h))
+        xn = _vi_add(x, p, alpha, 1.0, rr); x.free(); x = xn
+        rn = _vi_add(r, Ap, -alpha, 1.0, rr); r.free(); Ap.free(); r = rn
+        rs_new = D.dot(r.h, r.h)
+        pn = _vi_add(r, p, _safe_div(rs_new, rs), 1.0, rr); p.free(); p = pn
+        rs = rs_new
+    r.free(); p.free()
+    return x
+
+
+def _gmres(op, b: _Vec, x: _Vec, tol, krylovdim: int, maxiter: int, rr: int) -> _Vec:
+    """Restarted GMRES(krylovdim), modified Gram-Schmidt, the small least-squares problems per train on the host."""
+    B = b.h.batch
+    for outer in range(maxiter):
+        Ax = op(x)
+        r = _vi_add(b, Ax, -1.0, 1.0, rr); Ax.free()
+        beta = D.norm(r.h)
+        if np.all(beta <= tol):
+            r.free()
+            break
+        V = [_scale(r, _safe_div(1.0, beta))]; r.free()
+        H = np.zeros((B, krylovdim + 1, krylovdim))
+        m = 0
+        for j in range(krylovdim):
+            w = op(V[j])
+            for i in range(j + 1):
+                hij = D.dot(V[i].h, w.h)
+                H[:, i, j] = hij
+                wn = _vi_add(w, V[i], -hij, 1.0, rr); w.free(); w = wn
+            hn = D.norm(w.h)
+            H[:, j + 1, j] = hn
+            m = j + 1
+            if np.all(hn <= 1e-300) or j + 1 == krylovdim:
+                w.free()
+                break
+            V.append(_scale(w, _safe_div(1.0, hn))); w.free()
+        ycoef = np.zeros((B, m))
+        for t in range(B):
+            e1 = np.zeros(m + 1); e1[0] = beta[t]
+            ycoef[t] = np.linalg.lstsq(H[t, : m + 1, :m], e1, rcond=None)[0]
+        for j in range(m):
+            xn = _vi_add(x, V[j], ycoef[:, j], 1.0, rr); x.free(); x = xn
+        for v in V:
+            v.free()
+    return x
+
+
+def krylov_linsolve(A, b: DeviceTT, guess: DeviceTT, max_bond: int = 0, krylov_solver: str = "auto", krylovdim: int = 8,
+                    maxiter: int = 20, rtol: float = 1.0e-8, atol: float = 1.0e-12, tol=None, issymmetric: bool = False,
+                    ishermitian=None, isposdef: bool = False) -> DeviceTT:
+    """src/solvers/euler.jl:34-74 on device-resident batches (A: TToperator or DeviceTTO; every train its own system)."""
+    ishermitian = issymmetric if ishermitian is None else ishermitian
+    dA = A if isinstance(A, DeviceTTO) else DeviceTTO(A)
+    solver = "cg" if (krylov_solver == "auto" and isposdef and (issymmetric or ishermitian)) else krylov_solver   # :56
+    if solver == "auto":
+        solver = "bicgstab" if max_bond > 0 else "gmres"                                                             # :17
+    if solver not in ("bicgstab", "gmres", "cg"):
+        raise ValueError(f"Unknown Krylov solver: {krylov_solver}. Use :auto, :bicgstab, :cg, or :gmres.")           # :31
+    bv = _Vec(b, _ranks_of(b), own=False)
+    tol_value = np.maximum(atol, rtol * D.norm(b)) if tol is None else np.full(b.batch, float(tol))                   # :57
+    x0 = _Vec(guess, _ranks_of(guess), own=False)
+    x = _copy(x0)                                             # a working copy the iteration may free
+    op = _make_op(dA, max_bond)
+    if solver == "bicgstab":
+        x = _bicgstab(op, bv, x, tol_value, maxiter, max_bond)
+    elif solver == "cg":
+        x = _cg(op, bv, x, tol_value, krylovdim * maxiter, max_bond)                                                 # :28
+    else:
+        x = _gmres(op, bv, x, tol_value, krylovdim, maxiter, max_bond)
+    return x.h
+
+
+def _implicit_stepper(A: TToperator, u0: DeviceTT, guess: DeviceTT, steps, normalize, tt_solver, max_bond, crank, kw) -> DeviceTT:
+    if tt_solver != "krylov":
+        if tt_solver in ("mals", "als", "dmrg"):
+            raise NotImplementedError(f"tt_solver={tt_solver!r}: ALS/MALS/DMRG local solves are outside this backend (SURVEY §8 f1)")
+        raise ValueError(f"Unknown TT solver: {tt_solver}")
+    from .constructors import id_tto
+    I = id_tto(A.N)
+    sol, own = u0, False
+    for h in steps:
+        if crank:
+            lhs = _tto_add(I, _tto_scale(-h / 2, A))                                  # I - (h/2) A      (:156)
+            rhs_op = DeviceTTO(_tto_add(I, _tto_scale(h / 2, A)))                     # (I + (h/2) A) * solution
+            rhs, _ = _apply(rhs_op, sol, _ranks_of(sol))
+        else:
+            lhs = _tto_add(I, _tto_scale(-h, A))                                      # M = I - h A      (:113)
+            rhs = sol
+        nxt = krylov_linsolve(lhs, rhs, guess, max_bond=max_bond, **kw)
+        if crank:
+            rhs.free()
+        if normalize:
+            D.scale_batch(1.0 / D.norm(nxt), nxt, nxt)                                 # next / norm(next)
+        v = _round(_Vec(nxt, _ranks_of(nxt)), max_bond)                               # tt_compress!(next, max_bond) : orthogonalize(next)
+        if own:
+            sol.free()
+        sol, own, guess = v.h, True, v.h
+    return sol
+
+
+def implicit_euler_method(A: TToperator, u0: DeviceTT, guess: DeviceTT, steps, normalize: bool = True, tt_solver: str = "krylov",
+                          max_bond: int = 0, **kw) -> DeviceTT:
+    """src/solvers/euler.jl:98-140 (tt_solver = "krylov"; the return_error branch is not built)."""
+    return _implicit_stepper(A, u0, guess, steps, normalize, tt_solver, max_bond, False, kw)
+
+
+def crank_nicholson_method(A: TToperator, u0: DeviceTT, guess: DeviceTT, steps, normalize: bool = True, tt_solver: str = "krylov",
+                           max_bond: int = 0, **kw) -> DeviceTT:
+    """src/solvers/euler.jl:142-190 (tt_solver = "krylov"; the return_error branch is not built)."""
+    return _implicit_stepper(A, u0, guess, steps, normalize, tt_solver, max_bond, True, kw)

@@ -646,3 +646,58 @@ def test_rk4_and_euler_device_chains(T):
     K1 = Ad @ ud; K2 = Ad @ (ud + h / 2 * K1); K3 = Ad @ (ud + h / 2 * K2); K4 = Ad @ (ud + h * K3)
     refv = ud + h / 6 * (K1 + 2 * K2 + 2 * K3 + K4)
     assert np.linalg.norm(T.qtt_to_vector(one) - refv) / np.linalg.norm(refv) < 1e-6
+
+
+def _dense_op(A):
+    return O.qtto_to_matrix(to_oracle(A))
+
+
+def _nabla(T, d):
+    return T.toeplitz_to_qtto(1.0, 0.0, -1.0, d)            # src/tt_operators.jl:276-278
+
+
+@pytest.mark.parametrize("case", ["cn_gmres_default", "cn_nonsymmetric", "cn_bicgstab_bounded", "ie_cg"])
+def test_krylov_linsolve_steppers_match_dense_solves(T, case):
+    """krylov_linsolve + crank_nicholson_method / implicit_euler_method with tt_solver="krylov" on handles
+    (src/solvers/euler.jl:34-190), checked the way the reference checks them: against the dense solve
+    (test/test_euler.jl:105-240: rel error 1e-8, 1e-7 for the bounded BiCGStab case, rank bound).  KrylovKit itself is a
+    third-party dependency outside the reference tree: iterates are parity-unpinned, the solution is pinned."""
+    from ttn_amd import solvers as S
+    rng_seed = {"cn_gmres_default": 1, "cn_nonsymmetric": 2, "cn_bicgstab_bounded": 3, "ie_cg": 4}[case]
+    steps = [0.05]
+    if case == "cn_gmres_default":
+        d, A, kw, bound, tol_err = 4, None, dict(tol=1.0e-12), 0, 1.0e-8
+        A = S._tto_scale(0.1, T.Delta(d))
+    elif case == "cn_nonsymmetric":
+        d = 4
+        A, kw, bound, tol_err = S._tto_scale(0.1, _nabla(T, d)), dict(tol=1.0e-12), 0, 1.0e-8
+        assert not np.allclose(_dense_op(A), _dense_op(A).T)
+    elif case == "cn_bicgstab_bounded":
+        d = 5
+        A, bound, tol_err = S._tto_scale(0.1, _nabla(T, d)), 8, 1.0e-7
+        kw = dict(krylov_solver="bicgstab", maxiter=30, rtol=1.0e-10, atol=1.0e-12)
+    else:
+        d = 3
+        A, bound, tol_err = S._tto_scale(0.1, T.id_tto(d)), 0, 1.0e-8
+        kw = dict(isposdef=True, issymmetric=True, tol=1.0e-12)
+    B = 2
+    u0s = [T.rand_tt((2,) * d, 2, seed=rng_seed * 10 + b) for b in range(B)]
+    du = T.DeviceTT((2,) * d, u0s[0].ttv_rks, batch=B)
+    for b in range(B):
+        du.upload(b, u0s[b])
+    if case == "ie_cg":
+        sol = S.implicit_euler_method(A, du, du, steps, normalize=False, tt_solver="krylov", **kw)
+    else:
+        sol = S.crank_nicholson_method(A, du, du, steps, normalize=False, tt_solver="krylov", max_bond=bound, **kw)
+    Ad = _dense_op(A)
+    I = np.eye(Ad.shape[0])
+    for b in range(B):
+        ud = O.qtt_to_vector(to_oracle(u0s[b]))
+        ref = np.linalg.solve(I - steps[0] * Ad, ud) if case == "ie_cg" else np.linalg.solve(I - 0.5 * steps[0] * Ad, (I + 0.5 * steps[0] * Ad) @ ud)
+        got = sol.download(b)
+        err = np.linalg.norm(T.qtt_to_vector(got) - ref) / np.linalg.norm(ref)
+        assert err < tol_err, (case, b, err)
+        if bound:
+            assert max(got.ttv_rks) <= bound
+    with pytest.raises(ValueError):                              # ArgumentError in the reference (euler.jl:31)
+        S.implicit_euler_method(A, du, du, steps, normalize=False, tt_solver="krylov", krylov_solver="unknown")
