@@ -701,3 +701,29 @@ def test_krylov_linsolve_steppers_match_dense_solves(T, case):
             assert max(got.ttv_rks) <= bound
     with pytest.raises(ValueError):                              # ArgumentError in the reference (euler.jl:31)
         S.implicit_euler_method(A, du, du, steps, normalize=False, tt_solver="krylov", krylov_solver="unknown")
+
+
+def test_randomized_apply_compress_parity(T):
+    """60 random problems (d 2..10, dims 2..4, x ranks 1..19, operator ranks 1..3, max_bond 1..23, truncerr in {0, 1e-10, 1e-6,
+    1e-3}) through the fused ttn_apply_compress: ranks exact, tensor 1e-9 against the oracle.  (tests/diag_fuzz.py runs the
+    same generator for any count; 400 cases were clean on the round-1 build.)"""
+    rng = np.random.default_rng(1)
+    for it in range(60):
+        d = int(rng.integers(2, 11))
+        dims = tuple(int(v) for v in rng.integers(2, 5, size=d))
+        xr = int(rng.integers(1, 20))
+        oprks = [1] + [int(v) for v in rng.integers(1, 4, size=d - 1)] + [1]
+        A = T.TToperator(d, [np.asfortranarray(rng.standard_normal((dims[k], dims[k], oprks[k], oprks[k + 1]))) for k in range(d)],
+                         dims, oprks, [0] * d)
+        x = T.rand_tt(dims, xr, seed=int(rng.integers(1, 10 ** 6)))
+        mb = int(rng.integers(1, 24))
+        te = float(rng.choice([0.0, 0.0, 1e-10, 1e-6, 1e-3]))
+        ref = O.tt_compress_(O.apply(to_oracle(A), to_oracle(x)), mb, truncerr=te)
+        cap = [a * c for a, c in zip(A.tto_rks, x.ttv_rks)]
+        need, _ = T.device.compress_rank_bound(dims, cap, mb)
+        dy = T.DeviceTT(dims, [max(a, b) for a, b in zip(cap, need)])
+        T.device.apply_compress(T.DeviceTTO(A), T.DeviceTT.from_host(x), dy, mb, te)
+        T.device.compress_status(dy)
+        got = dy.download()
+        assert got.ttv_rks == ref.ttv_rks, (it, dims, xr, oprks, mb, te)
+        assert tt_rel_diff(to_oracle(got), ref) <= 1e-9, (it, dims, xr, oprks, mb, te)
