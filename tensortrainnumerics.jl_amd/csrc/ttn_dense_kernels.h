@@ -551,6 +551,67 @@ __device__ inline void lq_lds_whole(int p, int qc, const double* src, int lds_, 
     __syncthreads();
 }
 
+// The same with the explicit thin Q' (p x q, orthonormal rows, M = L Q'): factor in LDS, then E = [I 0] times
+// H_{p-1} ... H_0 in a second LDS image (2*p*q doubles in all: 64x128 cores of rank-64 trains fit).  In place: M2 receives L.
+// Ts (>= 128 doubles): tau_r; Ss (>= 256 doubles): beta_r and the scale 1/(alpha - beta) of the stored reflectors.
+__device__ inline void lq_lds_whole_q(int p, int q, double* M2, int ld, double* Qout, double* A, double* Ss, double* Ts) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    double* E = A + (long long)p * q;
+    double* scl = Ss + 128;
+    __syncthreads();
+    for (int e = tid; e < p * q; e += TTN_WG) {
+        const int r = e / q, c = e % q;
+        A[e] = M2[(long long)r * ld + c];
+        E[e] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int r = 0; r < p; ++r) {
+        const double* row = A + (long long)r * q;
+        double s = 0.0;
+        for (int c = r + 1 + lane; c < q; c += 64) { const double v = row[c]; s = fma(v, v, s); }
+        const double xnorm2 = wave64_sum_fast(s);
+        const double alpha = row[r];
+        double tau = 0.0, scal = 0.0, beta = alpha;
+        if (xnorm2 > 0.0) {
+            beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha);
+            tau = (beta - alpha) / beta;
+            scal = 1.0 / (alpha - beta);
+        }
+        if (tid == 0) { Ss[r] = beta; scl[r] = scal; Ts[r] = tau; }
+        for (int i = r + 1 + wave; tau != 0.0 && i < p; i += nwaves) {
+            double* ri = A + (long long)i * q;
+            double w = 0.0;
+            for (int c = r + 1 + lane; c < q; c += 64) w = fma(ri[c], row[c], w);
+            w = fma(scal, wave64_sum_fast(w), ri[r]);
+            const double tws = tau * w * scal;
+            for (int c = r + 1 + lane; c < q; c += 64) ri[c] = fma(-tws, row[c], ri[c]);
+            if (lane == 0) ri[r] -= tau * w;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < p * p; e += TTN_WG) {                 // L into M2 (the caller reads c <= r only)
+        const int r = e / p, c = e % p;
+        if (c <= r) M2[(long long)r * ld + c] = (c == r) ? Ss[r] : A[(long long)r * q + c];
+    }
+    // E <- E H_r for r = p-1 .. 0: rows i < r are still unit vectors orthogonal to v_r, so only rows i >= r change
+    for (int r = p - 1; r >= 0; --r) {
+        const double* row = A + (long long)r * q;               // v_r = [0.., 1 at r, row[c] * scl[r] for c > r]
+        const double tau = Ts[r], sc = scl[r];
+        for (int i = r + wave; tau != 0.0 && i < p; i += nwaves) {
+            double* ei = E + (long long)i * q;
+            double w = 0.0;
+            for (int c = r + 1 + lane; c < q; c += 64) w = fma(ei[c], row[c], w);
+            w = fma(sc, wave64_sum_fast(w), ei[r]);
+            const double tws = tau * w * sc;
+            for (int c = r + 1 + lane; c < q; c += 64) ei[c] = fma(-tws, row[c], ei[c]);
+            if (lane == 0) ei[r] -= tau * w;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < p * q; e += TTN_WG) Qout[e] = E[e];
+    __syncthreads();
+}
+
 __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, double* Vb, double* Wb, double* Tst, double* Qout,
                                            double* lds_gemm, double* Ts, double* Ss, double* taus, double* red) {
     // arguments of an out-of-line function arrive in VGPRs: pin the workgroup-uniform ones to SGPRs
@@ -560,6 +621,10 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
     const int rr = min(p, q);
 #ifndef TTN_NO_LDS_LQ
+    if (Qout && rr == p && p <= 128 && 2LL * p * q <= GEMM_LDS_DOUBLES) {       // small cores: factor AND explicit Q' in LDS
+        lq_lds_whole_q(p, q, M2, ld, Qout, lds_gemm, Ss, Ts);
+        return;
+    }
     // ---- matrices that fit the LDS whole (the small H-route steps of a sweep: 96x128, 64x128, ...): ONE "panel", no
     //      trailing GEMMs at all.  Wider ones with p <= 88 rows go through the LDS in column chunks of width w >= 2p
     //      (TSQR): L_i of every chunk is written back side by side, [L_1 L_2 ...] is factored again until one chunk is left
