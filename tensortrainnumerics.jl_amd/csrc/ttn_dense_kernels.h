@@ -1204,45 +1204,61 @@ __device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* f
     __syncthreads();
     double pmin = dmax;                                  // tracked by wave 0 (every lane sees every pivot)
     int bad = 0;
+    // (a) diagonal block j0, wave 0, in REGISTERS: lane (li, lk) holds D[li][lk + 4q], q = 0..3.  Per column one LDS round
+    //     trip: the owners publish the unscaled column, every lane reads the pivot, its row's and its columns' entries and
+    //     applies the rank-1 update to its four elements.  A lone wave issues one fp64 instruction per ~9 clk, so the step
+    //     is written with as few as possible: no per-element predicates.  Entries above the diagonal are PUBLISHED as zero,
+    //     which makes the update of an already final column (c < jj) vanish by itself; the unpublished upper entries a lane
+    //     holds just carry bounded garbage that is never read or written back.
+#define CHOL_DIAG_BLOCK(J0)                                                                                         \
+    {                                                                                                               \
+        const int jb_ = (n - (J0) < 16) ? n - (J0) : 16;                                                            \
+        lds_f64* D = G + (J0) * 128 + (J0);              /* D[c*128 + i] */                                          \
+        lds_f64* colbuf = invd + 16;                     /* red[16..31] */                                           \
+        double e[4];                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) { const int c = lk + 4 * q; e[q] = (li < jb_ && c <= li) ? D[c * 128 + li] : 0.0; } \
+        _Pragma("unroll") for (int jj = 0; jj < 16; ++jj) {                                                         \
+            if (jj >= jb_) break;                                                                                   \
+            if (lk == (jj & 3)) colbuf[li] = (li >= jj) ? e[jj >> 2] : 0.0;                                         \
+            __builtin_amdgcn_wave_barrier();                                                                        \
+            const double d = colbuf[jj], ali = colbuf[li];                                                          \
+            double ac[4];                                                                                           \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) ac[q] = colbuf[lk + 4 * q];                               \
+            if (!(d > dmin)) { if (lane == 0) *flag = 1; break; }                                                   \
+            pmin = fmin(pmin, d);                                                                                   \
+            const double rs = fast_rsqrt2(d);                                                                       \
+            const double lli = ali * rs, nl = -lli * rs;                                                            \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) e[q] = fma(nl, ac[q], e[q]);                              \
+            /* column jj is final: l_ij = a_ij / sqrt(d) below the diagonal, sqrt(d) = d * rs on it */              \
+            if (lk == (jj & 3) && li >= jj) e[jj >> 2] = lli;                                                       \
+            if (lane == 0) invd[jj] = rs;                                                                           \
+            __builtin_amdgcn_wave_barrier();                                                                        \
+        }                                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) { const int c = lk + 4 * q; if (li < jb_ && c <= li) D[c * 128 + li] = e[q]; } \
+    }
+    // (c) one 16x16 tile (tr >= tc) of the trailing update A22 -= L21 L21^T of panel j0, by one wave, straight from LDS
+#define CHOL_TILE(TILE)                                                                                             \
+    {                                                                                                               \
+        int tr = 0, base = 0;                                                                                       \
+        while (base + tr + 1 <= (TILE)) { base += tr + 1; ++tr; }      /* tile = tr(tr+1)/2 + tc */                  \
+        const int tc = (TILE) - base;                                                                               \
+        const int r0 = s0 + 16 * tr, c0 = s0 + 16 * tc;                                                             \
+        mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};                                                          \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                             \
+            const lds_f64* col = G + (j0 + 4 * t + lk) * 128;                                                       \
+            const double av = (r0 + li < n) ? col[r0 + li] : 0.0;                                                   \
+            const double bv = (c0 + li < n) ? col[c0 + li] : 0.0;                                                   \
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                       \
+            const int row = r0 + lk + 4 * reg, colj = c0 + li;                                                      \
+            if (row < n && colj < n && row >= colj) G[colj * 128 + row] -= acc[reg];                                \
+        }                                                                                                           \
+    }
+    if (wave == 0) CHOL_DIAG_BLOCK(0)
     for (int j0 = 0; j0 < n; j0 += 16) {
         const int jb = (n - j0 < 16) ? n - j0 : 16;
-        // ---- (a) diagonal block, wave 0, in REGISTERS: lane (li, lk) holds D[li][lk + 4q], q = 0..3.  Per column one LDS
-        //      round trip: the owners publish the unscaled column, every lane reads the pivot, its row's and its columns'
-        //      entries and applies the rank-1 update to its four elements ----
-        if (wave == 0) {
-            lds_f64* D = G + j0 * 128 + j0;              // D[c*128 + i]
-            lds_f64* colbuf = invd + 16;                 // red[16..31]
-            double e[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int c = lk + 4 * q; e[q] = (li < jb && c <= li) ? D[c * 128 + li] : 0.0; }
-            // A lone wave issues one fp64 instruction per ~9 clk, so the step is written with as few as possible: no
-            // per-element predicates.  Entries above the diagonal are PUBLISHED as zero, which makes the update of an
-            // already final column (c < jj) vanish by itself; the unpublished upper entries a lane holds just carry
-            // bounded garbage that is never read or written back.
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                if (jj >= jb) break;
-                if (lk == (jj & 3)) colbuf[li] = (li >= jj) ? e[jj >> 2] : 0.0;
-                __builtin_amdgcn_wave_barrier();
-                const double d = colbuf[jj], ali = colbuf[li];
-                double ac[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ac[q] = colbuf[lk + 4 * q];
-                if (!(d > dmin)) { if (lane == 0) *flag = 1; break; }
-                pmin = fmin(pmin, d);
-                const double rs = fast_rsqrt2(d);
-                const double lli = ali * rs, nl = -lli * rs;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[q] = fma(nl, ac[q], e[q]);
-                // column jj is final: l_ij = a_ij / sqrt(d) below the diagonal, sqrt(d) = d * rs on it (the update above left 0 there)
-                if (lk == (jj & 3) && li >= jj) e[jj >> 2] = lli;
-                if (lane == 0) invd[jj] = rs;
-                __builtin_amdgcn_wave_barrier();
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int c = lk + 4 * q; if (li < jb && c <= li) D[c * 128 + li] = e[q]; }
-        }
-        __syncthreads();
+        __syncthreads();                                 // diagonal block j0 factored (by wave 0, during the previous trailing update)
         if (*flag) { bad = 1; break; }
         const int s0 = j0 + jb, sr = n - s0;             // first row / number of rows below the block
         if (sr > 0) {                                    // then jb == 16
@@ -1262,30 +1278,20 @@ __device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* f
                 for (int c = 0; c < 16; ++c) G[(j0 + c) * 128 + r] = a[c];
             }
             __syncthreads();
-            // ---- (c) trailing update, lower-triangle tiles (tr >= tc) ----
+            // ---- (c) trailing update with LOOKAHEAD: wave 0 takes tile 0 (= the next diagonal block) and factors it right
+            //      away — the long dependent chain of (a) — while the other waves do the remaining tiles ----
             const int nt = (sr + 15) >> 4, ntiles = nt * (nt + 1) / 2;
-            for (int tile = wave; tile < ntiles; tile += nwaves) {
-                int tr = 0, base = 0;
-                while (base + tr + 1 <= tile) { base += tr + 1; ++tr; }      // tile = tr(tr+1)/2 + tc
-                const int tc = tile - base;
-                const int r0 = s0 + 16 * tr, c0 = s0 + 16 * tc;
-                mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const lds_f64* col = G + (j0 + 4 * t + lk) * 128;
-                    const double av = (r0 + li < n) ? col[r0 + li] : 0.0;
-                    const double bv = (c0 + li < n) ? col[c0 + li] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int row = r0 + lk + 4 * reg, colj = c0 + li;
-                    if (row < n && colj < n && row >= colj) G[colj * 128 + row] -= acc[reg];
-                }
+            if (wave == 0) {
+                CHOL_TILE(0)
+                CHOL_DIAG_BLOCK(s0)
+            } else {
+                for (int tile = wave; tile < ntiles; tile += nwaves - 1) CHOL_TILE(tile)
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
+#undef CHOL_DIAG_BLOCK
+#undef CHOL_TILE
     // pivots lie between the extreme eigenvalues of G, so dmax/pmin is a LOWER bound of cond(G) = cond(M)^2
     if (tid == 0) *pivmin_out = (!bad && pmin > 0.0) ? dmax / pmin : 1.0e300;
     for (int e = tid; e < n * 128; e += TTN_WG) { const int c = e >> 7, i = e & 127; if (i < c) G[c * 128 + i] = 0.0; }
