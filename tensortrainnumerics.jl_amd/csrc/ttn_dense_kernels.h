@@ -1190,18 +1190,31 @@ __device__ __noinline__ int wg_jacobi_blocked256(int m, int p, double* Xg, int l
 //   (c) the trailing matrix gets A22 -= L21 L21^T by fp64 MFMA, one 16x16 tile of the lower triangle per wave and trip,
 //       operands read straight from the LDS image.
 // -------------------------------------------------------------------------------------------------
-__device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
+// NTEAM = 2 (n <= 64): the workgroup splits into two teams of 8 waves that factor TWO matrices at once (team t: the matrix
+// at Gg + t*64*128, scratch red + 32*t, result slot pivmin_out[t]) — the route-F step needs chol(A'^T A') and chol(B' B'^T),
+// and a factorisation is dominated by the dependent pivot chain of one wave, so two in parallel cost about what one does.
+// The barriers are workgroup-wide: both teams run the same control flow (same n); a bad pivot in either stops both.
+template <int NTEAM>
+__device__ int chol_lds128_teams(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
     n = uni32(n); Gg = unip(Gg); red = unip(red); flag = unip(flag); pivmin_out = unip(pivmin_out);     // VGPR arguments -> SGPRs
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    constexpr int WPT = TTN_NWAVES / NTEAM;              // waves per team
+    const int lane = threadIdx.x & 63;
+    const int team = (threadIdx.x >> 6) / WPT, wave = (threadIdx.x >> 6) % WPT, nwaves = WPT;
+    const int tid = threadIdx.x - team * WPT * 64;       // thread index inside the team
     const int li = lane & 15, lk = lane >> 4;
-    lds_f64* G = (lds_f64*)Gg;
-    lds_f64* invd = (lds_f64*)red;                       // 1 / l_kk of the current panel (red[0..15], free between reductions)
+    lds_f64* G = (lds_f64*)Gg + team * 64 * 128;
+    lds_f64* invd = (lds_f64*)red + 32 * team;           // 1 / l_kk of the current panel ([0..15]) and the column buffer ([16..31])
     double dmax = 0.0;
-    for (int j = tid; j < n; j += TTN_WG) dmax = fmax(dmax, G[j * 128 + j]);
-    dmax = wg_max(dmax, red);
-    const double dmin = (double)n * DBL_EPSILON * dmax;
-    if (tid == 0) *flag = 0;
+    if (wave == 0) {
+        for (int j = lane; j < n; j += 64) dmax = fmax(dmax, G[j * 128 + j]);
+        dmax = wave_max(dmax);
+        if (lane == 0) invd[0] = dmax;
+    }
+    if (threadIdx.x == 0) *flag = 0;
     __syncthreads();
+    dmax = invd[0];
+    __syncthreads();
+    const double dmin = (double)n * DBL_EPSILON * dmax;
     double pmin = dmax;                                  // tracked by wave 0 (every lane sees every pivot)
     int bad = 0;
     // (a) diagonal block j0, wave 0, in REGISTERS: lane (li, lk) holds D[li][lk + 4q], q = 0..3.  Per column one LDS round
@@ -1293,10 +1306,18 @@ __device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* f
 #undef CHOL_DIAG_BLOCK
 #undef CHOL_TILE
     // pivots lie between the extreme eigenvalues of G, so dmax/pmin is a LOWER bound of cond(G) = cond(M)^2
-    if (tid == 0) *pivmin_out = (!bad && pmin > 0.0) ? dmax / pmin : 1.0e300;
-    for (int e = tid; e < n * 128; e += TTN_WG) { const int c = e >> 7, i = e & 127; if (i < c) G[c * 128 + i] = 0.0; }
+    if (tid == 0) pivmin_out[team] = (!bad && pmin > 0.0) ? dmax / pmin : 1.0e300;
+    for (int e = tid; e < n * 128; e += WPT * 64) { const int c = e >> 7, i = e & 127; if (i < c) G[c * 128 + i] = 0.0; }
     __syncthreads();
     return bad;
+}
+
+__device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
+    return chol_lds128_teams<1>(n, Gg, red, flag, pivmin_out);
+}
+// two n x n matrices (n <= 64) at Gg and Gg + 64*128; red: 64 doubles; pivmin_out: 2 doubles
+__device__ TTN_NI_CHOL int wg_chol2_lds128(int n, double* Gg, double* red64, int* flag, double* pivmin_out2 /*LDS*/) {
+    return chol_lds128_teams<2>(n, Gg, red64, flag, pivmin_out2);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1586,19 +1607,28 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
             wg_gemm(rm, rm, p, tview(Ap), Ap, Gav, 1.0 / (sA * sA), 0.0, lds);          // A'^T A'
             wg_gemm(rm, rm, q, Bp, tview(Bp), Gbv, 1.0 / (sB * sB), 0.0, lds);          // B' B'^T
             PROF_MARK(8)
-            // L_A
-            for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.ldsX[e] = S.Ga[e];
-            __syncthreads();
-            ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
-            for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.Ga[e] = S.ldsX[e];
-            __syncthreads();
-        }
-        if (ok) {
-            for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.ldsX[e] = S.Gb[e];
-            __syncthreads();
-            ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
-            for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.Gb[e] = S.ldsX[e];
-            __syncthreads();
+            if (rm <= 64) {
+                // both Cholesky factorisations at once, one per half of the workgroup (wg_chol2_lds128)
+                for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) { S.ldsX[e] = S.Ga[e]; S.ldsX[64 * 128 + e] = S.Gb[e]; }
+                __syncthreads();
+                ok = wg_chol2_lds128(rm, S.ldsX, S.Ts, S.iflag, S.scal + 1) == 0;     // Ts: 256 doubles of LDS, free here
+                for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) { S.Ga[e] = S.ldsX[e]; S.Gb[e] = S.ldsX[64 * 128 + e]; }
+                __syncthreads();
+            } else {
+                // L_A
+                for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.ldsX[e] = S.Ga[e];
+                __syncthreads();
+                ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
+                for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.Ga[e] = S.ldsX[e];
+                __syncthreads();
+                if (ok) {
+                    for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.ldsX[e] = S.Gb[e];
+                    __syncthreads();
+                    ok = wg_chol_lds128(rm, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
+                    for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) S.Gb[e] = S.ldsX[e];
+                    __syncthreads();
+                }
+            }
         }
         int r = 0, rk = 0;
         if (ok) {
