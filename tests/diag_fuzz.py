@@ -7,15 +7,16 @@ from oracle import tt_oracle as O
 from tests.helpers import to_oracle, tt_rel_diff
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"          # larger ranks: merged short sides up to 256, wide matrices
 bad = 0
 for it in range(N):
-    d = int(rng.integers(2, 11))
+    d = int(rng.integers(4, 9)) if BIG else int(rng.integers(2, 11))
     dims = tuple(int(v) for v in rng.integers(2, 5, size=d))
-    xr = int(rng.integers(1, 20))
+    xr = int(rng.integers(8, 44)) if BIG else int(rng.integers(1, 20))
     oprks = [1] + [int(v) for v in rng.integers(1, 4, size=d - 1)] + [1]
     A = T.TToperator(d, [np.asfortranarray(rng.standard_normal((dims[k], dims[k], oprks[k], oprks[k + 1]))) for k in range(d)], dims, oprks, [0] * d)
     x = T.rand_tt(dims, xr, seed=int(rng.integers(1, 10 ** 6)))
-    mb = int(rng.integers(1, 24))
+    mb = int(rng.integers(8, 120)) if BIG else int(rng.integers(1, 24))
     te = float(rng.choice([0.0, 0.0, 1e-10, 1e-6, 1e-3]))
     try:
         ref = O.tt_compress_(O.apply(to_oracle(A), to_oracle(x)), mb, truncerr=te)
