@@ -130,6 +130,15 @@ end
 # Device-resident chains (Krylov / RK4 inner loops, src/solvers/euler.jl:55,199-204) use the handle API:
 #   h = Ref{Ptr{Cvoid}}(); ccall((:ttn_tt_create, LIB), Cint, (Int64, Ptr{Int64}, Ptr{Int64}, Int64, Ref{Ptr{Cvoid}}), ...)
 #   ccall((:ttn_apply_compress, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Int64), A, x, y, r, 0.0, 1)
-# so that tt_compress!(A*x, r) never crosses PCIe.
+# so that tt_compress!(A*x, r) never crosses PCIe (ttn_apply_compress fuses the apply into the first L->R sweep: A*x is
+# never written to HBM).
+#
+# Core-wise sharded chains (one segment of the chain per GPU / Julia worker, INTEGRATION.md §5): a segment is an ordinary
+# handle with open boundary ranks; one direction of a sweep over the local bonds and the boundary-core hand-off are
+#   ccall((:ttn_sweep, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Float64), y, k_first, k_last, max_bond, truncerr)
+#   ccall((:ttn_tt_core_extent, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), y, k, n, bl, br)
+#   ccall((:ttn_tt_core_export, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int64}), y, k, devbuf, devrks)   # -> ncclSend
+#   ccall((:ttn_tt_core_import, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int64}, Int64, Int64), y, k, devbuf, devrks, bl, br)
+# (k, k_first, k_last 1-based like _tt_bond_truncate!; devbuf / devrks are device pointers).
 
 end # module
