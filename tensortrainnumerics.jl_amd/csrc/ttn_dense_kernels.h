@@ -6,6 +6,22 @@
 // train for the whole sweep (no inter-workgroup synchronisation anywhere); a batch of trains fills
 // the 256 CUs.  All matrices are addressed through `View`s (2-level strides) so the reference's
 // permutedims/reshape copies (src/tt_tools.jl:746-767) become index arithmetic.
+//
+// Map of this file (top to bottom):
+//   wg_sum / wg_max                 workgroup reductions
+//   wg_gemm                         fp64 MFMA GEMM on Views: tiled (2 LDS stages, offset tables) and one-shot small form
+//   lq_lds_whole(_q), wg_lq_blocked Householder LQ: whole matrix in LDS / TSQR column chunks / blocked compact WY
+//   wg_jacobi_cols                  one-sided Jacobi in global memory (fallback for short sides > 256)
+//   jacobi_lds128_body, wg_jacobi_lds128, wg_jacobi_blocked256
+//                                   the LDS Jacobi (register-resident stationary columns, DPP hand-over of the moving
+//                                   block, MFMA all-reduce) and its blocked driver for short sides 129..256
+//   chol_lds128_teams               blocked LDS Cholesky with lookahead, one or two matrices at once
+//   wg_svd_cols / wg_rank_rule / wg_check_diag, wg_materialize_core / wg_fused_merge, wg_bond_step, k_compress
+//                                   the bond step (routes F / G / H, fused apply) and the persistent sweep kernel
+//   k_dot, k_selftest_gemm, k_bench_gemm, k_bench_lds
+// Rule learnt the hard way: arguments of out-of-line device functions arrive in VGPRs, and anything
+// loaded from memory the kernel also writes is a per-lane value to the compiler — pin workgroup-uniform values with
+// uni32/uni64/unip, or every derived size, view and pointer occupies VGPRs and ends up in the stack frame.
 #pragma once
 #include "ttn_common.h"
 #include <float.h>
