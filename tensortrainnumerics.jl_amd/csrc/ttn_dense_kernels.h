@@ -628,6 +628,68 @@ __device__ inline void lq_lds_whole_q(int p, int q, double* M2, int ld, double* 
     __syncthreads();
 }
 
+// Block-reflector update with everything but C in LDS:  C (rows x len, row-major in GLOBAL memory, leading dimension ldc)
+//     C <- C - ((C V^T) Top) V,   V (16 x len, LDS, leading dimension ldv), Top = T or T^T (16 x 16, LDS, row-major).
+// One wave per tile of 16 rows of C, three fp64-MFMA passes (W = C V^T: len/4 MFMAs; W' = W Top: 4; C -= W' V: len/4), no
+// workgroup barrier inside (a wave only needs its own W).  Replaces three generic GEMM calls per panel whose inner /
+// outer dimension is 16 (prologue-dominated: ~150 k clk per panel against ~25 k here).  Rows of V beyond the panel height
+// must be zero.  Wl: 256 doubles of LDS per wave.
+__device__ inline int blkref_ldv(int len) { return ((len + 27) / 32) * 32 + 4; }     // >= len, == 4 mod 32: the 16 V rows a pass-1 read touches spread over the banks
+__device__ inline void wg_block_reflector_apply(int rows, int len, double* Cg, int ldc, const double* Vl_, int ldv, const double* Tl_,
+                                                bool transT, double* Wl_) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = TTN_WG >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const lds_f64* V = (const lds_f64*)Vl_;
+    const lds_f64* T = (const lds_f64*)Tl_;
+    lds_f64* W = (lds_f64*)Wl_ + wave * 256;
+    const int ntile = (rows + 15) >> 4;
+    for (int tile = wave; tile < ntile; tile += nwaves) {
+        const int r0 = tile << 4;
+        const bool rok = r0 + li < rows;
+        const double* crow = Cg + (long long)(r0 + (rok ? li : 0)) * ldc;
+        mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < len; k0 += 4) {                                   // W = C_tile V^T
+            const int kk = k0 + lk;
+            const double a = (rok && kk < len) ? crow[kk] : 0.0;
+            const double b = (kk < len) ? V[li * ldv + kk] : 0.0;               // B[k][j] = V[j][k]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) W[(lk + 4 * reg) * 16 + li] = acc[reg];
+        __builtin_amdgcn_wave_barrier();
+        mfma_acc_t acc2 = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                                           // W' = W Top
+            const int kk = 4 * t + lk;
+            const double a = W[li * 16 + kk];
+            const double b = transT ? T[li * 16 + kk] : T[kk * 16 + li];        // B[k][j] = Top[k][j]
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) W[(lk + 4 * reg) * 16 + li] = acc2[reg];
+        __builtin_amdgcn_wave_barrier();
+        double at[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) at[t] = W[li * 16 + 4 * t + lk];
+        for (int c0 = 0; c0 < len; c0 += 16) {                                  // C_tile -= W' V
+            const bool cok = c0 + li < len;
+            mfma_acc_t acc3 = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double b = cok ? V[(4 * t + lk) * ldv + c0 + li] : 0.0;
+                acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(at[t], b, acc3, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = r0 + lk + 4 * reg;
+                if (row < rows && cok) Cg[(long long)row * ldc + c0 + li] -= acc3[reg];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, double* Vb, double* Wb, double* Tst, double* Qout,
                                            double* lds_gemm, double* Ts, double* Ss, double* taus, double* red) {
     // arguments of an out-of-line function arrive in VGPRs: pin the workgroup-uniform ones to SGPRs
@@ -668,11 +730,15 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
         const int jb = min(QR_NB, rr - j0);
         const int len = q - j0;
         const bool in_lds = (long long)jb * len <= GEMM_LDS_DOUBLES;
+        // fast trailing update (wg_block_reflector_apply): the panel is factored in LDS with the padded leading dimension
+        // ldv and then turned into the explicit V in place; 16 rows of V + 256 doubles of W per wave must fit the region
+        const int ldv = blkref_ldv(len);
+        const bool fastp = (long long)QR_NB * ldv + 256 * (TTN_WG / 64) <= GEMM_LDS_DOUBLES;
         double* Pn = in_lds ? lds_gemm : (M2 + (long long)j0 * ld + j0);
-        const int ldp = in_lds ? len : ld;
+        const int ldp = fastp ? ldv : (in_lds ? len : ld);
         __syncthreads();
         if (in_lds) {
-            for (int e = tid; e < jb * len; e += TTN_WG) { const int r = e / len, c = e - r * len; Pn[e] = M2[(long long)(j0 + r) * ld + j0 + c]; }
+            for (int e = tid; e < jb * len; e += TTN_WG) { const int r = e / len, c = e - r * len; Pn[(long long)r * ldp + c] = M2[(long long)(j0 + r) * ld + j0 + c]; }
             __syncthreads();
         }
         // ---- panel factorisation ----
@@ -701,18 +767,41 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
             __syncthreads();
         }
         // ---- write the panel back (L entries, beta on the diagonal, scaled v to the right) and the explicit V ----
-        for (int e = tid; e < jb * len; e += TTN_WG) {
+        for (int e = tid; e < QR_NB * len; e += TTN_WG) {
             const int r = e / len, c = e - r * len;
-            const double x = Pn[(long long)r * ldp + c];
-            const double out = (c < r) ? x : ((c == r) ? betas[r] : x * scl[r]);
-            Vb[(long long)r * len + c] = (c < r) ? 0.0 : ((c == r) ? 1.0 : out);
-            M2[(long long)(j0 + r) * ld + j0 + c] = out;
+            if (r < jb) {
+                const double x = Pn[(long long)r * ldp + c];
+                const double out = (c < r) ? x : ((c == r) ? betas[r] : x * scl[r]);
+                const double vv = (c < r) ? 0.0 : ((c == r) ? 1.0 : out);
+                if (fastp) Pn[(long long)r * ldp + c] = vv;               // the LDS panel becomes V (same element, same thread)
+                else Vb[(long long)r * len + c] = vv;
+                M2[(long long)(j0 + r) * ld + j0 + c] = out;
+            } else if (fastp) Pn[(long long)r * ldp + c] = 0.0;            // rows of V beyond a short last panel
         }
         __syncthreads();
+        if (fastp) {                                                      // betas / scl (which live in Ss) have been consumed
+            for (int e = tid; e < QR_NB * QR_NB; e += TTN_WG) Ss[e] = 0.0;
+            __syncthreads();
+        }
         const int rows_t = p - (j0 + jb);
         if (rows_t <= 0 && !Qout) break;
         View Vv = mkview(Vb, plain(len), plain(1));                       // jb x len
         // S = V V^T, then T (upper triangular): T[j][j] = tau_j ; T[i][j] = -tau_j * sum_{l=i}^{j-1} T[i][l] S[l][j]
+        if (fastp) {
+            // split-K MFMA: wave w sums its slice of k, the 16 partial tiles meet in Ss by LDS atomic adds
+            const int li = lane & 15, lk = lane >> 4;
+            const int kc = (((len + nwaves - 1) / nwaves) + 3) & ~3;
+            const lds_f64* V = (const lds_f64*)Pn;
+            mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+            for (int k0 = wave * kc; k0 < min(len, (wave + 1) * kc); k0 += 4) {
+                const int kk = k0 + lk;
+                const double a = (kk < len) ? V[li * ldp + kk] : 0.0;      // A[i][k] = V[i][k], B[k][j] = V[j][k]: the same register
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) atomicAdd(&Ss[(lk + 4 * reg) * QR_NB + li], acc[reg]);
+            __syncthreads();
+        } else
         wg_gemm(jb, jb, len, Vv, tview(Vv), mkview(Ss, plain(QR_NB), plain(1)), 1.0, 0.0, lds_gemm);
         if (tid < QR_NB) {                                // lane i builds row i of T: it only needs its own row
             const int i = tid;
@@ -728,7 +817,9 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
         }
         __syncthreads();
         if (Qout) for (int e = tid; e < QR_NB * QR_NB; e += TTN_WG) Tst[(long long)(j0 / QR_NB) * QR_NB * QR_NB + e] = Ts[e];
-        if (rows_t > 0) {
+        if (rows_t > 0 && fastp) {
+            wg_block_reflector_apply(rows_t, len, M2 + (long long)(j0 + jb) * ld + j0, ld, Pn, ldp, Ts, false, Pn + (long long)QR_NB * ldp);
+        } else if (rows_t > 0) {
             // W = C V^T (rows_t x jb), C = M2[j0+jb:, j0:] ; W <- W T ; C <- C - W V
             View Cv = mkview(M2 + (long long)(j0 + jb) * ld + j0, plain(ld), plain(1));
             View Wv = mkview(Wb, plain(QR_NB), plain(1));
@@ -755,6 +846,15 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
     for (int j0 = ((rr - 1) / QR_NB) * QR_NB; j0 >= 0; j0 -= QR_NB) {
         const int jb = min(QR_NB, rr - j0);
         const int len = q - j0;
+        const int ldv = blkref_ldv(len);
+        const bool fastp = (long long)QR_NB * ldv + 256 * (TTN_WG / 64) <= GEMM_LDS_DOUBLES;
+        __syncthreads();
+        if (fastp) {
+            for (int e = tid; e < QR_NB * len; e += TTN_WG) {
+                const int r = e / len, c = e - r * len;
+                lds_gemm[(long long)r * ldv + c] = (r >= jb || c < r) ? 0.0 : ((c == r) ? 1.0 : M2[(long long)(j0 + r) * ld + j0 + c]);
+            }
+        } else
         for (int e = tid; e < jb * len; e += TTN_WG) {
             const int r = e / len, c = e - r * len;
             Vb[e] = (c < r) ? 0.0 : ((c == r) ? 1.0 : M2[(long long)(j0 + r) * ld + j0 + c]);
@@ -762,6 +862,10 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
         for (int e = tid; e < QR_NB * QR_NB; e += TTN_WG) Ts[e] = Tst[(long long)(j0 / QR_NB) * QR_NB * QR_NB + e];
         __syncthreads();
         const int rows_q = rr - j0;
+        if (fastp) {
+            wg_block_reflector_apply(rows_q, len, Qout + (long long)j0 * q + j0, q, lds_gemm, ldv, Ts, true, lds_gemm + (long long)QR_NB * ldv);
+            continue;
+        }
         View Vv = mkview(Vb, plain(len), plain(1));
         View Qs = mkview(Qout + (long long)j0 * q + j0, plain(q), plain(1));
         View Wv = mkview(Wb, plain(QR_NB), plain(1));
