@@ -1221,6 +1221,7 @@ __device__ TTN_NI_JACOBI int wg_jacobi_lds128(int m, int p, double* Xg, double* 
     lds_f64* nrm2 = (lds_f64*)nrm2g;
     if (m <= 32) return jacobi_lds128_body<1, 128>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
     if (m <= 64) return jacobi_lds128_body<2, 128>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
+    if (m <= 96) return jacobi_lds128_body<3, 128>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);     // the 96-column ramp step
     return jacobi_lds128_body<4, 128>(m, p, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out);
 }
 
