@@ -115,6 +115,17 @@ int ttn_tt_core_extent(ttn_tt_t h, int64_t k, int64_t* doubles_per_train, int64_
 int ttn_tt_core_export(ttn_tt_t h, int64_t k, double* dev_buf, int64_t* dev_rks2);
 int ttn_tt_core_import(ttn_tt_t h, int64_t k, const double* dev_buf, const int64_t* dev_rks2, int64_t bound_left, int64_t bound_right);
 
+/* --- site-swap chains: the two-site SVD step with the physical indices of the two cores exchanged
+ * (_ttm_swap!, src/tt_operations.jl:365-382; _swap_adjacent_sites, src/qtt_tools.jl:660-695): factors U and S*Vt.
+ * All physical dimensions of the train must be equal (QTT: 2) and n * rank capacity <= 256.
+ * ttn_hadamard_ttm: z = hadamard_ttm(x, y; tol, rmax) (src/tt_operations.jl:398-422; d(d-1)/2 swaps + d site-wise
+ *   contractions, rank rule = the relative tail norm of tt_cross_interpolation.jl:149-166).  work_cap = rank capacity of the
+ *   2d working slots; a rank above it (or above z's capacity) is reported by ttn_compress_status as TTN_ERR_CAPACITY.
+ * ttn_swap_sites: the swap list of reorder (src/qtt_tools.jl:763-769) in place; swaps[i] = k (1-based) exchanges sites
+ *   k and k+1; rank rule = count(s > threshold * s[1]) (at least 1), or every singular value when threshold == 0. */
+int ttn_hadamard_ttm(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z, double tol, int64_t rmax, int64_t work_cap);
+int ttn_swap_sites(ttn_tt_t x, int64_t nswaps, const int64_t* swaps, double threshold);
+
 /* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);
 

@@ -36,6 +36,8 @@ __all__ = [
     "apply", "dot", "norm", "euclidean_distance", "hadamard", "add", "add_", "scale",
     "sub", "div", "orthogonalize", "svdtrunc", "svdtrunc_shadowed", "tt_bond_truncate_",
     "tt_compress_", "copy_tt", "rk4_method", "euler_method",
+    "ttm_swap_", "ttm_contract_", "hadamard_ttm", "swap_adjacent_sites", "bubble_sort_swaps", "reorder_perm",
+    "swap_sites_", "reorder",
 ]
 
 
@@ -544,6 +546,114 @@ def tt_compress_(psi: TTvector, max_bond: int, truncerr: float = 0.0, sweeps: in
         for k in range(psi.N - 1, 0, -1):
             tt_bond_truncate_(psi, k, max_bond=max_bond, truncerr=truncerr, faithful=faithful, svals_out=svals_out)
     return psi
+
+
+# --------------------------------------------------------------------------------------
+# hadamard_ttm — src/tt_operations.jl:363-422 (SVD with the relative criterion of the
+# effective _svdtrunc; "Eq. (10) of arXiv:2410.19747" per the source comment)
+# --------------------------------------------------------------------------------------
+def ttm_swap_(cores: list, rks: list, j: int, tol: float = 0.0, rmax: int = 2 ** 62) -> int:
+    """_ttm_swap!(cores, rks, j) (src/tt_operations.jl:365-382); j is 1-based."""
+    A, B = cores[j - 1], cores[j]                   # (dA, rL, rM), (dB, rM, rR)
+    dA, rL, _ = A.shape
+    dB, _, rR = B.shape
+    C = np.einsum("xma,yan->xymn", A, B)            # C[sA, sB, m, n]
+    # permutedims(C, (3, 2, 1, 4)) -> (rL, dB, dA, rR), column-major reshape: rows (m, sB), cols (sA, n)
+    mat = np.reshape(C.transpose(2, 1, 0, 3), (rL * dB, dA * rR), order="F")
+    U, sv, Vt = svdtrunc(mat, max_bond=rmax, truncerr=tol)
+    r = U.shape[1]
+    cores[j - 1] = np.reshape(U, (rL, dB, r), order="F").transpose(1, 0, 2).copy()                       # (dB, rL, r)
+    cores[j] = np.reshape(sv[:, None] * Vt, (r, dA, rR), order="F").transpose(1, 0, 2).copy()           # (dA, r, rR)
+    rks[j] = r
+    return r
+
+
+def ttm_contract_(cores: list, rks: list, p: int) -> None:
+    """_ttm_contract!(cores, rks, p) (src/tt_operations.jl:384-396); p is 1-based."""
+    A, B = cores[p - 1], cores[p]
+    Pi = np.einsum("sma,san->smn", A, B)
+    cores[p - 1] = Pi
+    del cores[p]
+    del rks[p]
+
+
+def hadamard_ttm(x: TTvector, y: TTvector, tol: float = 1.0e-14, rmax: int = 2 ** 62) -> TTvector:
+    """src/tt_operations.jl:398-422."""
+    assert tuple(x.ttv_dims) == tuple(y.ttv_dims), "Incompatible TT dimensions"
+    d = x.N
+    cores = [np.array(c, dtype=float) for c in x.ttv_vec]
+    for k in range(1, d + 1):
+        cores.append(np.transpose(y.ttv_vec[d - k], (0, 2, 1)).copy())
+    rks = list(x.ttv_rks) + list(reversed(list(y.ttv_rks)))[1:]
+    for it in range(1, d + 1):
+        for j in range(d, d - it + 1, -1):          # j = d : -1 : (d - it + 2)
+            ttm_swap_(cores, rks, j, tol=tol, rmax=rmax)
+        ttm_contract_(cores, rks, d - it + 1)
+    return TTvector(d, cores, tuple(x.ttv_dims), [int(r) for r in rks], [0] * d)
+
+
+# --------------------------------------------------------------------------------------
+# QTT reorder — src/qtt_tools.jl:660-775 (vector form)
+# --------------------------------------------------------------------------------------
+def swap_adjacent_sites(A: np.ndarray, B: np.ndarray, threshold: float = 0.0):
+    """_swap_adjacent_sites (src/qtt_tools.jl:660-695)."""
+    d1, rl, _ = A.shape
+    d2, _, rr = B.shape
+    C = np.einsum("xlm,ymr->xylr", A, B)            # C[s1, s2, l, r]
+    # permutedims(C, (2, 3, 1, 4)) -> (s2, l, s1, r); reshape(d2*rl, d1*rr) column-major
+    M = np.reshape(C.transpose(1, 2, 0, 3), (d2 * rl, d1 * rr), order="F")
+    U, sv, Vt = sla.svd(M, full_matrices=False, lapack_driver="gesdd")
+    if threshold > 0:
+        r_new = max(1, int(np.count_nonzero(sv > threshold * sv[0])))
+    else:
+        r_new = len(sv)
+    U, sv, Vt = U[:, :r_new], sv[:r_new], Vt[:r_new, :]
+    new_A = np.reshape(U, (d2, rl, r_new), order="F").copy()
+    new_B = np.reshape(sv[:, None] * Vt, (r_new, d1, rr), order="F").transpose(1, 0, 2).copy()
+    return new_A, new_B
+
+
+def bubble_sort_swaps(perm: Sequence[int]) -> List[int]:
+    """_bubble_sort_swaps (src/qtt_tools.jl:705-718): 1-based adjacent swap positions."""
+    p = list(perm)
+    swaps = []
+    n = len(p)
+    for i in range(1, n + 1):
+        for j in range(1, n - i + 1):
+            if p[j - 1] > p[j]:
+                p[j - 1], p[j] = p[j], p[j - 1]
+                swaps.append(j)
+    return swaps
+
+
+def reorder_perm(n_dims: int, bits_per_dim: int, to_interleaved: bool) -> List[int]:
+    """The target-position vector of reorder (src/qtt_tools.jl:740-757): perm[src] = tgt, 0-based values."""
+    N = n_dims * bits_per_dim
+    perm = [0] * N
+    for dd in range(1, n_dims + 1):
+        for b in range(bits_per_dim):
+            if to_interleaved:
+                src, tgt = (dd - 1) * bits_per_dim + b, b * n_dims + (dd - 1)
+            else:
+                src, tgt = b * n_dims + (dd - 1), (dd - 1) * bits_per_dim + b
+            perm[src] = tgt
+    return perm
+
+
+def swap_sites_(x: TTvector, swaps: Sequence[int], threshold: float = 0.0) -> TTvector:
+    """The swap loop of reorder (src/qtt_tools.jl:762-773) on a plain TTvector, in place."""
+    for k in swaps:
+        a, b = swap_adjacent_sites(x.ttv_vec[k - 1], x.ttv_vec[k], threshold=threshold)
+        x.ttv_vec[k - 1], x.ttv_vec[k] = a, b
+    x.ttv_rks = [1] + [int(c.shape[2]) for c in x.ttv_vec]
+    x.ttv_ot = [0] * x.N
+    return x
+
+
+def reorder(x: TTvector, n_dims: int, bits_per_dim: int, to_interleaved: bool, threshold: float = 0.0) -> TTvector:
+    """reorder(q, new_ordering; threshold) (src/qtt_tools.jl:733-775) for a QTT vector given as its TTvector plus metadata."""
+    y = copy_tt(x)
+    return swap_sites_(y, bubble_sort_swaps(reorder_perm(n_dims, bits_per_dim, to_interleaved)), threshold=threshold)
 
 
 # --------------------------------------------------------------------------------------

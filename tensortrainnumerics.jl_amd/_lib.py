@@ -65,6 +65,8 @@ SIGNATURES = {
     "ttn_dot": (C.c_int, [handle, handle, p_f64]),
     "ttn_norm": (C.c_int, [handle, p_f64]),
     "ttn_hadamard": (C.c_int, [handle, handle, handle]),
+    "ttn_hadamard_ttm": (C.c_int, [handle, handle, handle, C.c_double, i64, i64]),
+    "ttn_swap_sites": (C.c_int, [handle, i64, p_i64, C.c_double]),
     "ttn_add": (C.c_int, [handle, handle, handle]),
     "ttn_scale": (C.c_int, [C.c_double, handle, handle]),
     "ttn_scale_batch": (C.c_int, [p_f64, handle, handle]),

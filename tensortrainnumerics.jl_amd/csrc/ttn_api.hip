@@ -144,6 +144,8 @@ int ttn_init(int device) {
     // the compress / orthogonalize kernels use more than the default 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compress), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(COMPRESS_LDS_BYTES)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_swap_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_orthogonalize), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(ORTHO_LDS_BYTES)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dot), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -658,6 +660,7 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     P.sv_steps = steps;
     P.status = g_status;
     P.sweep_stats = g_status + psi->batch;
+    P.rank_rule = 0;
     P.fused = (fuseA && fusex) ? 1 : 0;
     if (P.fused) { P.op = fuseA->dev(); P.x = fusex->dev(); }
     else { memset(&P.op, 0, sizeof(P.op)); memset(&P.x, 0, sizeof(P.x)); }
@@ -771,11 +774,132 @@ int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, do
     return launch_compress(y, 0, max_bond, truncerr, sweeps, 0, 0, A, x);
 }
 
+// ---- site-swap chains: hadamard_ttm and reorder -----------------------------------------------------
+// Launch of k_swap_chain.  `ops` = (type, slotA, slotB) triples; kind 1 works in an arena of 2d uniform slots carved out of
+// the scratch allocation, kind 2 in place on the handle's own slots.
+static int launch_chain(int kind, ttn_tt_t x, ttn_tt_t y, ttn_tt_t z, int n, int nslots, int64_t work_cap, const std::vector<int>& ops,
+                        const std::vector<int>& final_slots, double tol, int64_t rmax, int rank_rule) {
+    static std::vector<int> h_tab;                      // must outlive the async upload below
+    ttn_tt_t ref = (kind == 1) ? x : z;
+    const int batch = ref->batch;
+    const long long pmax = (long long)n * work_cap, qmax = pmax;
+    if (pmax > 256) return fail(TTN_ERR_UNSUPPORTED, "site-swap chain: n * rank capacity must be <= 256");
+    const long long per_compress = 2 * pmax * qmax + QR_NB * qmax + pmax * QR_NB + 2 * pmax * pmax + 4 * pmax + 64 + 6 * 128 * 128;
+    const long long slot_doubles = (kind == 1) ? (long long)n * work_cap * work_cap : 0;
+    const long long srk_stride = 2 * nslots + 2;
+    const long long per_train = per_compress + srk_stride + (long long)nslots * slot_doubles;
+    const size_t tab_ints = ops.size() + final_slots.size();
+    HIPCHK(hipStreamSynchronize(g_stream));            // h_tab of the previous call is no longer in flight
+    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * batch + sizeof(int) * tab_ints + 64);
+    if (rc) return rc;
+    rc = ensure_batch_bufs(batch);
+    if (rc) return rc;
+    double* base = (double*)g_scratch;
+    int* d_tab = (int*)(base + (size_t)per_train * batch);
+    h_tab.assign(ops.begin(), ops.end());
+    h_tab.insert(h_tab.end(), final_slots.begin(), final_slots.end());
+    HIPCHK(hipMemcpyAsync(d_tab, h_tab.data(), sizeof(int) * tab_ints, hipMemcpyHostToDevice, g_stream));
+    ChainArgs Q;
+    memset(&Q, 0, sizeof(Q));
+    CompressArgs& P = Q.C;
+    if (kind == 2) P.tt = z->dev();
+    P.max_bond = rmax;
+    P.truncerr = tol;
+    P.sweeps = 1;
+    P.scratch = base;
+    P.scratch_stride = per_train;
+    P.pmax = (int)pmax; P.qmax = (int)qmax;
+    P.sv_out = nullptr; P.sv_steps = 0;
+    P.status = g_status;
+    P.sweep_stats = g_status + batch;
+    P.prof = nullptr;
+    { const char* e = getenv("TTN_JTOL"); P.jtol_mult = e ? atof(e) : 1.0; }
+    { const char* e = getenv("TTN_JNEG"); P.jneg_mult = e ? atof(e) : 1.0; }
+    P.fast = 0;
+    P.fused = 0;
+    P.rank_rule = rank_rule;
+    Q.kind = kind;
+    Q.n = n; Q.nslots = nslots; Q.nops = (int)(ops.size() / 3); Q.d = (kind == 1) ? x->d : z->d;
+    Q.ops = d_tab;
+    Q.final_slots = d_tab + ops.size();
+    Q.arena = base + per_compress + srk_stride;        // per train: [compress scratch | slot ranks | slots]
+    Q.arena_stride = per_train;
+    Q.slot_doubles = slot_doubles;
+    Q.cap = (int)work_cap;
+    Q.srk = (long long*)(base + per_compress);
+    Q.srk_stride = per_train;                           // in units of 8 bytes, like the doubles
+    if (kind == 1) { Q.x = x->dev(); Q.y = y->dev(); Q.z = z->dev(); }
+    hipLaunchKernelGGL(k_swap_chain, dim3(batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, Q);
+    HIPCHK(hipGetLastError());
+    return TTN_OK;
+}
+
+int ttn_hadamard_ttm(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z, double tol, int64_t rmax, int64_t work_cap) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!x || !y || !z) return fail(TTN_ERR_ARG, "null handle");
+    if (!same_dims(x->dims, y->dims) || !same_dims(x->dims, z->dims)) return fail(TTN_ERR_DIMS, "Incompatible TT dimensions");
+    if (x->batch != y->batch || x->batch != z->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
+    if (z == x || z == y) return fail(TTN_ERR_ARG, "ttn_hadamard_ttm: output must not alias an input");
+    if (rmax < 1 || work_cap < 1 || tol < 0.0) return fail(TTN_ERR_ARG, "bad tol / rmax / work_cap");
+    const int d = x->d;
+    const int64_t n = x->dims[0];
+    for (int k = 0; k < d; ++k) if (x->dims[k] != n) return fail(TTN_ERR_UNSUPPORTED, "ttn_hadamard_ttm: all physical dimensions must be equal");
+    if (2 * d > 2 * TTN_MAX_D) return fail(TTN_ERR_UNSUPPORTED, "chain too long");
+    for (int m = 0; m <= d; ++m)
+        if (x->bound[m] > work_cap || y->bound[m] > work_cap) return fail(TTN_ERR_CAPACITY, "ttn_hadamard_ttm: work_cap below an input rank");
+    // the reference's loops (tt_operations.jl:414-420) as ops on fixed slots.  With L0 = 2d (iter 1) or d-iter+2 (later) the
+    // logical core l (1-based) lives in slot l (l <= L0) or l - L0 + d + 1: the contraction of iteration i frees slot d+2-i.
+    std::vector<int> ops, fin;
+    auto slot = [&](int iter, int l) { const int L0 = (iter == 1) ? 2 * d : d - iter + 2; return (l <= L0 ? l : l - L0 + d + 1) - 1; };
+    for (int iter = 1; iter <= d; ++iter) {
+        for (int j = d; j >= d - iter + 2; --j) { ops.push_back(0); ops.push_back(slot(iter, j)); ops.push_back(slot(iter, j + 1)); }
+        const int pc = d - iter + 1;
+        ops.push_back(1); ops.push_back(slot(iter, pc)); ops.push_back(slot(iter, pc + 1));
+    }
+    for (int l = 1; l <= d; ++l) fin.push_back(slot(d + 1, l));
+    int rc = launch_chain(1, x, y, z, (int)n, 2 * d, work_cap, ops, fin, tol, rmax, 0);
+    if (rc) return rc;
+    for (int m = 0; m <= d; ++m) z->bound[m] = std::min<int64_t>(z->cap[m], std::min<int64_t>(work_cap, rmax));
+    z->bound[0] = 1; z->bound[d] = 1;
+    std::fill(z->ot.begin(), z->ot.end(), 0);
+    return TTN_OK;
+}
+
+int ttn_swap_sites(ttn_tt_t x, int64_t nswaps, const int64_t* swaps, double threshold) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!x || nswaps < 0 || (nswaps > 0 && !swaps) || threshold < 0.0) return fail(TTN_ERR_ARG, "bad argument");
+    const int d = x->d;
+    const int64_t n = x->dims[0];
+    for (int k = 0; k < d; ++k) if (x->dims[k] != n) return fail(TTN_ERR_UNSUPPORTED, "ttn_swap_sites: all physical dimensions must be equal");
+    int64_t capmax = 1;
+    for (int m = 0; m <= d; ++m) capmax = std::max(capmax, x->cap[m]);
+    std::vector<int> ops, fin;
+    std::vector<int64_t> bnd = x->bound;
+    for (int64_t i = 0; i < nswaps; ++i) {
+        const int64_t k = swaps[i];
+        if (k < 1 || k >= d) return fail(TTN_ERR_BOND_INDEX, "k must be in 1:(N-1)");
+        // length(F.S) = min(n r_{k-1}, n r_{k+1}) is kept whole when threshold == 0 (qtt_tools.jl:681-685)
+        const int64_t full = std::min(n * bnd[k - 1], n * bnd[k + 1]);
+        if (threshold == 0.0 && full > x->cap[k]) return fail(TTN_ERR_CAPACITY, "ttn_swap_sites: a bond rank grows beyond the handle's capacity");
+        bnd[k] = std::min(full, x->cap[k]);
+        ops.push_back(0); ops.push_back((int)k - 1); ops.push_back((int)k);
+    }
+    if (nswaps == 0) return TTN_OK;
+    int rc = launch_chain(2, nullptr, nullptr, x, (int)n, d, capmax, ops, fin, threshold, (int64_t)1 << 62, 1);
+    if (rc) return rc;
+    x->bound = bnd;
+    std::fill(x->ot.begin(), x->ot.end(), 0);
+    return TTN_OK;
+}
+
 // status of the last dense kernel (synchronises): returns TTN_ERR_NO_CONVERGENCE if any train failed
 static int check_status(int batch) {
     std::vector<int> st(batch);
     HIPCHK(hipMemcpyAsync(st.data(), g_status, sizeof(int) * batch, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
+    for (int b = 0; b < batch; ++b) if (st[b] == 2) return fail(TTN_ERR_CAPACITY, "a rank grew beyond the capacity of its slot (site-swap chain)");
     for (int b = 0; b < batch; ++b) if (st[b]) return fail(TTN_ERR_NO_CONVERGENCE, "Jacobi SVD hit its sweep limit");
     return TTN_OK;
 }

@@ -1467,6 +1467,8 @@ struct CompressArgs {
     int fused;
     TTODev op;
     TTDev x;
+    int rank_rule;         // 0: relative tail norm (_svdtrunc, tt_cross_interpolation.jl:149-166); 1: count(s > truncerr * s[1]), at least 1
+                           //    (_swap_adjacent_sites, src/qtt_tools.jl:680-685)
 };
 
 #define COMPRESS_LDS_X_DOUBLES (128 * 128)
@@ -1513,7 +1515,14 @@ __device__ int wg_svd_cols(const CompressArgs& P, const BondCtx& S, int pj, doub
 __device__ int wg_rank_rule(const CompressArgs& P, const BondCtx& S, int ns, int plen, double s0) {
     if (threadIdx.x == 0) {
         int r = plen;
-        if (P.truncerr > 0.0) {
+        if (P.rank_rule == 1) {
+            if (P.truncerr > 0.0) {
+                r = 0;
+                const double thr = P.truncerr * (S.sigs[0] * s0);
+                for (int i = 0; i < ns; ++i) r += (S.sigs[i] * s0 > thr) ? 1 : 0;
+                if (r < 1) r = 1;
+            }
+        } else if (P.truncerr > 0.0) {
             double n2 = 0.0;
             for (int i = 0; i < ns; ++i) { const double s = S.sigs[i] * s0; n2 = fma(s, s, n2); }
             const double nrm = sqrt(n2);
@@ -1646,18 +1655,24 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
 //   H            robust: blocked Householder LQ of M (or M itself if square), Jacobi on its columns.
 // F and G square the condition number, so they are taken only if sigma_max/sigma_min <= FAST_KAPPA_MAX and are
 // verified a posteriori (Rf Rf^T = Sigma, Lf^T Lf = Sigma to FAST_CHECK_TOL); otherwise the step is redone by H.
-__device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, double* lds, bool virt = false /* core k+1 is A_{k+1} x_{k+1}, not yet written */) {
+// SWAP != 0 is the site-swap variant of the same step (_ttm_swap!, src/tt_operations.jl:365-382, and _swap_adjacent_sites,
+// src/qtt_tools.jl:660-695; both cores have the same physical dimension here): the merged matrix takes its row index from
+// (left rank, physical index of core k+1) and its column index from (physical index of core k, right rank), and the factors
+// are U and S*Vt instead of U sqrt(S), sqrt(S) Vt.  Only route H is used (the swapped matrices are rank deficient by design).
+struct BondIO {
+    double *ck, *ck1;            // the two cores (slots)
+    int n1, n2, Dl, rm, Dr;      // physical dimensions and the three ranks
+    long long* rank_out;         // receives the new middle rank (SWAP: -1 if it exceeds `cap`; nothing is written then)
+    int cap;                     // SWAP only: largest middle rank the two slots can hold
+};
+template <int SWAP>
+__device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, const BondIO& io, int k, int step, double* lds, bool virt) {
     const int tid = threadIdx.x;
-    const TTDev& T = P.tt;
-    long long* rks = T.rks + (long long)b * (T.d + 1);
-    // the ranks are read from memory this kernel also writes, so the compiler treats them (and every view, size and pointer
-    // derived from them) as per-lane values: readfirstlane pins them to SGPRs — the bond step is full of calls, and every
-    // VGPR that is live across a call costs a slot of the stack frame (HBM traffic, profiles/README.md "traffic by step")
-    const int n1 = uni32(T.dims[k]), n2 = uni32(T.dims[k + 1]);
-    const int Dl = uni32((int)rks[k]), rm = uni32((int)rks[k + 1]), Dr = uni32((int)rks[k + 2]);
+    const int n1 = io.n1, n2 = io.n2;
+    const int Dl = io.Dl, rm = io.rm, Dr = io.Dr;
     const int mr = n1 * Dl, mc = n2 * Dr;
-    double* ck = T.data + (long long)b * T.stride + T.off[k];
-    double* ck1 = T.data + (long long)b * T.stride + T.off[k + 1];
+    double* ck = io.ck;
+    double* ck1 = io.ck1;
     // A_mat[(al + Dl*s1), ga] = core_k[s1, al, ga] ; B_mat[ga, (s2 + n2*be)] = core_{k+1}[s2, ga, be]
     const View Am = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));
     const View Bm = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * rm});
@@ -1710,7 +1725,7 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
     bool done = false;
 
     // =============================== route F: factored ===============================
-    if (P.fast && rm < p && rm <= 128 && rm >= 2) {
+    if (SWAP == 0 && P.fast && rm < p && rm <= 128 && rm >= 2) {
         // scales
         double sa = 0.0, sb = 0.0;
         for (long long e = tid; e < (long long)n1 * Dl * rm; e += TTN_WG) sa = fmax(sa, fabs(ck[e]));
@@ -1813,7 +1828,7 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
                     const int j = (int)(e / q), col = (int)(e % q);
                     Ro.p[ix(Ro.r, j) + ix(Ro.c, col)] = (j < rk) ? RfT[(long long)j * q + col] : 0.0;
                 }
-                if (tid == 0) rks[k + 1] = r;
+                if (tid == 0) *io.rank_out = r;
                 __syncthreads();
                 done = true;
                 route = 0;
@@ -1832,9 +1847,22 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
             merged = wg_fused_merge(P, b, k, p, q, Am, S.M, S.M2, pq, lds, S.scal + 6, S.red);
             if (!merged) wg_materialize_core(P, b, k + 1);
         }
-        if (!merged) wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds, S.scal + 6);
+        double mx_swap = 0.0;
+        if (SWAP != 0) {
+            // M[(m + Dl*sB), (sA + n1*nn)] = sum_a core_k[sA, m, a] * core_{k+1}[sB, a, nn]: one Dl x Dr x rm product per (sA, sB),
+            // written into its strided block of M (transposed when the merged matrix is tall)
+            for (int sA = 0; sA < n1; ++sA)
+                for (int sB = 0; sB < n2; ++sB) {
+                    const View Av = mkview(ck + sA, plain(n1), plain((long long)n1 * Dl));          // Dl x rm
+                    const View Bv = mkview(ck1 + sB, plain(n2), plain((long long)n2 * rm));         // rm x Dr
+                    if (wide) wg_gemm(Dl, Dr, rm, Av, Bv, mkview(S.M + (long long)Dl * sB * q + sA, plain(q), plain(n1)), 1.0, 0.0, lds, S.scal + 6);
+                    else wg_gemm(Dr, Dl, rm, tview(Bv), tview(Av), mkview(S.M + (long long)sA * q + (long long)Dl * sB, plain((long long)n1 * q), plain(1)), 1.0, 0.0, lds, S.scal + 6);
+                    mx_swap = fmax(mx_swap, unif64(S.scal[6]));
+                    __syncthreads();
+                }
+        } else if (!merged) wg_gemm(p, q, rm, Ap, Bp, Mv, 1.0, 0.0, lds, S.scal + 6);
         PROF_MARK(0)
-        const double mx = unif64(S.scal[6]);
+        const double mx = (SWAP != 0) ? mx_swap : unif64(S.scal[6]);
         const double s0 = (mx > 0.0) ? mx : 1.0;
         const double inv_s0 = 1.0 / s0;
         PROF_MARK(1)
@@ -1846,7 +1874,7 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
         // small merged matrices (the rank-ramp steps) fit the LDS whole: their Householder LQ needs no GEMM calls and costs
         // about what the Gram + Cholesky do, without the conditioning gamble — route H directly
         const bool lq_in_lds = (long long)p * q <= GEMM_LDS_DOUBLES || GEMM_LDS_DOUBLES / p >= 2 * p;     // whole, or TSQR chunks (wg_lq_blocked)
-        for (int attempt = (P.fast && need_lq && x_in_lds && p >= 2 && !lq_in_lds) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
+        for (int attempt = (SWAP == 0 && P.fast && need_lq && x_in_lds && p >= 2 && !lq_in_lds) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
             bool ok = true;
             if (attempt == 1) {
                 // =========================== route G: L = chol(M M^T) ===========================
@@ -1915,6 +1943,12 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
             PROF_MARK(3)
             if (!ok) continue;
             const int r = wg_rank_rule(P, S, p, p, s0);
+            if (SWAP != 0 && r > io.cap) {                                  // would not fit the slots: report, write nothing
+                if (tid == 0) { P.status[b] = 2; *io.rank_out = -1; }
+                __syncthreads();
+                done = true;
+                continue;
+            }
             if (attempt == 1) {
                 // Gram route: the KEPT block must be well conditioned (error ~ eps*kappa^2, verified below); the discarded
                 // singular values only matter to the rank rule, i.e. when truncerr > 0 (then all of them must qualify).
@@ -1939,8 +1973,12 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
                 const double sj = S.sigs[j];
                 const double xv = X[(long long)S.perm[j] * ldx + row];
                 const bool keep = (sj > 0.0) && (sj * sj > aneg);
-                const double lf = keep ? xv * (sq0 / sqrt(sj)) : 0.0;
-                const double us = keep ? xv * (sq0 / (sj * sqrt(sj))) : 0.0;
+                // x_j = sigma_j * (singular vector of the short side), in units of s0.  Compress: sqrt(S) on both sides.
+                // Swap: the LEFT core gets U, the right one S*Vt — the short side is the left one iff the matrix is wide.
+                double lf, us;
+                if (SWAP == 0) { lf = keep ? xv * (sq0 / sqrt(sj)) : 0.0; us = keep ? xv * (sq0 / (sj * sqrt(sj))) : 0.0; }
+                else if (wide) { lf = keep ? xv / sj : 0.0; us = keep ? xv * (s0 / sj) : 0.0; }
+                else { lf = keep ? xv * s0 : 0.0; us = keep ? xv / (sj * sj) : 0.0; }
                 Lo.p[ix(Lo.r, row) + ix(Lo.c, j)] = lf;
                 S.Us[(long long)j * p + row] = us;            // Us^T stored: (r x p) row-major
             }
@@ -1955,7 +1993,7 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
                     for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? S.sigs[i] * s0 : -1.0;
                 }
             }
-            if (tid == 0) rks[k + 1] = r;
+            if (tid == 0) *io.rank_out = r;
             __syncthreads();
             done = true;
             route = attempt;
@@ -1969,6 +2007,22 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
     }
     __syncthreads();
 #undef PROF_MARK
+}
+
+// tt_compress! form of the step: cores k, k+1 of train b of P.tt
+__device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k, int step, double* lds, bool virt = false /* core k+1 is A_{k+1} x_{k+1}, not yet written */) {
+    const TTDev& T = P.tt;
+    long long* rks = T.rks + (long long)b * (T.d + 1);
+    // the ranks are read from memory this kernel also writes, so the compiler treats them (and every view, size and pointer
+    // derived from them) as per-lane values: readfirstlane pins them to SGPRs — the bond step is full of calls, and every
+    // VGPR that is live across a call costs a slot of the stack frame (HBM traffic, profiles/README.md "traffic by step")
+    BondIO io;
+    io.n1 = uni32(T.dims[k]); io.n2 = uni32(T.dims[k + 1]);
+    io.Dl = uni32((int)rks[k]); io.rm = uni32((int)rks[k + 1]); io.Dr = uni32((int)rks[k + 2]);
+    io.ck = T.data + (long long)b * T.stride + T.off[k];
+    io.ck1 = T.data + (long long)b * T.stride + T.off[k + 1];
+    io.rank_out = rks + k + 1;
+    wg_bond_step_io<0>(P, b, io, k, step, lds, virt);
 }
 
 __global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {
@@ -1998,6 +2052,122 @@ __global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {
         wg_bond_step(P, b, k, step, lds, virt);
         if (P.prof && step < 120 && threadIdx.x == 0)            // bits 12..31 of the step word: kilo-cycles of the step
             P.prof[(long long)P.tt.batch * 16 + (long long)b * 120 + step] |= ((((long long)__builtin_amdgcn_s_memtime() - ts_) >> 10) & 0xFFFFF) << 12;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Site-swap chains: hadamard_ttm (src/tt_operations.jl:398-422) and QTT reorder (src/qtt_tools.jl:733-775).
+// Both are sequences of two-site swap SVDs (wg_bond_step_io<1>) on a chain of cores with one physical dimension n; the TTM
+// Hadamard product additionally contracts neighbours site-wise (_ttm_contract!, :384-396), which shortens the chain.  One
+// workgroup owns one train for the whole program; the host turns the reference's loops into a list of (type, slotA, slotB)
+// ops on fixed storage slots, so a deleted core is simply a slot no later op names.
+// -------------------------------------------------------------------------------------------------
+struct ChainArgs {
+    CompressArgs C;              // tolerance / rank rule / scratch / status (C.tt = the handle for kind 2)
+    int kind;                    // 1: hadamard_ttm (slots in `arena`, x and y copied in, result copied to z); 2: reorder in place
+    int n, nslots, nops, d;
+    const int* ops;              // device [nops][3]: type (0 swap, 1 contract), slotA, slotB
+    const int* final_slots;      // device [d] (kind 1): slots of the final chain, left to right
+    double* arena;               // kind 1: per train nslots * slot_doubles
+    long long arena_stride, slot_doubles;
+    int cap;                     // kind 1: rank capacity of every slot
+    long long* srk;              // per train [2*nslots + 2]: left ranks, right ranks, new-rank word
+    long long srk_stride;
+    TTDev x, y, z;               // kind 1
+};
+
+__global__ void __launch_bounds__(TTN_WG) k_swap_chain(ChainArgs Q) {
+    extern __shared__ double lds[];
+    const CompressArgs& P = Q.C;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = Q.n, ns = Q.nslots;
+    long long* srl = Q.srk + (long long)b * Q.srk_stride;
+    long long* srr = srl + ns;
+    long long* rword = srr + ns;
+    if (tid == 0) { P.status[b] = 0; P.sweep_stats[b] = 0; }
+    __syncthreads();
+    // ---- set-up ----
+    if (Q.kind == 1) {
+        const int d = Q.d;
+        const long long* xr = Q.x.rks + (long long)b * (d + 1);
+        const long long* yr = Q.y.rks + (long long)b * (d + 1);
+        for (int k = 0; k < d; ++k) {
+            const int rl = uni32((int)xr[k]), rr = uni32((int)xr[k + 1]);
+            const double* src = Q.x.data + (long long)b * Q.x.stride + Q.x.off[k];
+            double* dst = Q.arena + (long long)b * Q.arena_stride + (long long)k * Q.slot_doubles;
+            for (int e = tid; e < n * rl * rr; e += TTN_WG) dst[e] = src[e];
+            if (tid == 0) { srl[k] = rl; srr[k] = rr; }
+        }
+        for (int k = 0; k < d; ++k) {                          // slot d + k <- permutedims(y[d-1-k], (1,3,2))   (tt_operations.jl:411)
+            const int ky = d - 1 - k;
+            const int rl = uni32((int)yr[ky]), rr = uni32((int)yr[ky + 1]);
+            const double* src = Q.y.data + (long long)b * Q.y.stride + Q.y.off[ky];
+            double* dst = Q.arena + (long long)b * Q.arena_stride + (long long)(d + k) * Q.slot_doubles;
+            for (int e = tid; e < n * rl * rr; e += TTN_WG) {
+                const int s_ = e % n, t = e / n, a = t % rl, c = t / rl;
+                dst[s_ + n * (c + (long long)rr * a)] = src[e];
+            }
+            if (tid == 0) { srl[d + k] = rr; srr[d + k] = rl; }
+        }
+    } else {
+        const long long* rks = P.tt.rks + (long long)b * (P.tt.d + 1);
+        for (int k = tid; k < ns; k += TTN_WG) { srl[k] = rks[k]; srr[k] = rks[k + 1]; }
+    }
+    __syncthreads();
+    // ---- the program ----
+    bool alive = true;
+    for (int o = 0; o < Q.nops; ++o) {
+        if (!alive) break;
+        const int type = Q.ops[3 * o], sA = Q.ops[3 * o + 1], sB = Q.ops[3 * o + 2];
+        double* cA = (Q.kind == 1) ? Q.arena + (long long)b * Q.arena_stride + (long long)sA * Q.slot_doubles
+                                   : P.tt.data + (long long)b * P.tt.stride + P.tt.off[sA];
+        double* cB = (Q.kind == 1) ? Q.arena + (long long)b * Q.arena_stride + (long long)sB * Q.slot_doubles
+                                   : P.tt.data + (long long)b * P.tt.stride + P.tt.off[sB];
+        const int rL = uni32((int)srl[sA]), rM = uni32((int)srr[sA]), rR = uni32((int)srr[sB]);
+        if (type == 0) {
+            BondIO io;
+            io.ck = cA; io.ck1 = cB;
+            io.n1 = n; io.n2 = n; io.Dl = rL; io.rm = rM; io.Dr = rR;
+            io.rank_out = rword;
+            io.cap = (Q.kind == 1) ? Q.cap : uni32((int)P.tt.cap[sB]);
+            wg_bond_step_io<1>(P, b, io, sA, o, lds, false);
+            const int r = uni32((int)*rword);
+            if (r < 0) alive = false;
+            else if (tid == 0) { srr[sA] = r; srl[sB] = r; }
+            __syncthreads();
+        } else {
+            // Pi[s] = A[s] * B[s]   (rL x rM)(rM x rR) for every physical index s; the product replaces A's slot
+            double* tmp = P.scratch + (long long)b * P.scratch_stride;
+            for (int s_ = 0; s_ < n; ++s_) {
+                const View Av = mkview(cA + s_, plain(n), plain((long long)n * rL));
+                const View Bv = mkview(cB + s_, plain(n), plain((long long)n * rM));
+                const View Cv = mkview(tmp + s_, plain(n), plain((long long)n * rL));
+                wg_gemm(rL, rR, rM, Av, Bv, Cv, 1.0, 0.0, lds);
+            }
+            __syncthreads();
+            for (int e = tid; e < n * rL * rR; e += TTN_WG) cA[e] = tmp[e];
+            if (tid == 0) srr[sA] = rR;
+            __syncthreads();
+        }
+    }
+    // ---- results ----
+    if (Q.kind == 1) {
+        const int d = Q.d;
+        long long* zr = Q.z.rks + (long long)b * (d + 1);
+        if (alive) {
+            for (int k = 0; k < d; ++k) {
+                const int sl = Q.final_slots[k];
+                const int rl = uni32((int)srl[sl]), rr = uni32((int)srr[sl]);
+                if (rl > Q.z.cap[k] || rr > Q.z.cap[k + 1]) { if (tid == 0) P.status[b] = 2; alive = false; break; }
+                const double* src = Q.arena + (long long)b * Q.arena_stride + (long long)sl * Q.slot_doubles;
+                double* dst = Q.z.data + (long long)b * Q.z.stride + Q.z.off[k];
+                for (int e = tid; e < n * rl * rr; e += TTN_WG) dst[e] = src[e];
+                if (tid == 0) { zr[k] = rl; zr[k + 1] = rr; }
+            }
+        }
+    } else if (alive) {
+        long long* rks = P.tt.rks + (long long)b * (P.tt.d + 1);
+        for (int k = tid; k < ns; k += TTN_WG) rks[k + 1] = srr[k];
     }
 }
 

@@ -1,0 +1,88 @@
+"""Site-swap chains on the device: hadamard_ttm and QTT reorder.
+
+Both are sequences of the two-site swap SVD (csrc/ttn_dense_kernels.h: wg_bond_step_io<1>, k_swap_chain) — the same Jacobi
+SVD step as tt_compress!, with the physical indices of the two cores exchanged and factors U, S*Vt.  The index work (bubble
+sort network of reorder, the op list of hadamard_ttm) is integer work and bit-exact with the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+from . import _lib
+from .device import DeviceTT, compress_status
+from .tt import TTvector, _i64
+
+
+def bubble_sort_swaps(perm: Sequence[int]) -> List[int]:
+    """_bubble_sort_swaps (src/qtt_tools.jl:705-718): 1-based positions k of the adjacent swaps (k, k+1) that sort `perm`."""
+    p = list(perm)
+    out: List[int] = []
+    for done in range(len(p)):
+        for j in range(len(p) - 1 - done):
+            if p[j] > p[j + 1]:
+                p[j], p[j + 1] = p[j + 1], p[j]
+                out.append(j + 1)
+    return out
+
+
+def reorder_perm(n_dims: int, bits_per_dim: int, new_ordering: str) -> List[int]:
+    """Target position of every site (src/qtt_tools.jl:740-757): serial site (dim, bit) = dim*bits + bit, interleaved site
+    = bit*n_dims + dim (0-based)."""
+    assert new_ordering in ("interleaved", "serial"), "ordering must be :interleaved or :serial"
+    perm = [0] * (n_dims * bits_per_dim)
+    for dim in range(n_dims):
+        for bit in range(bits_per_dim):
+            ser, il = dim * bits_per_dim + bit, bit * n_dims + dim
+            if new_ordering == "interleaved":
+                perm[ser] = il
+            else:
+                perm[il] = ser
+    return perm
+
+
+# ---- device level ---------------------------------------------------------------------------------------------------
+def swap_sites_(x: DeviceTT, swaps: Sequence[int], threshold: float = 0.0) -> DeviceTT:
+    """In-place adjacent site swaps (1-based positions) on every train of the handle (src/qtt_tools.jl:762-769)."""
+    sw = [int(k) for k in swaps]
+    _lib.check(_lib.lib().ttn_swap_sites(x.h, len(sw), _i64(sw) if sw else None, float(threshold)))
+    return x
+
+
+def hadamard_ttm_(x: DeviceTT, y: DeviceTT, z: DeviceTT, tol: float = 1.0e-14, rmax: int = 2 ** 62, work_cap: int = 0) -> DeviceTT:
+    """z = hadamard_ttm(x, y; tol, rmax) (src/tt_operations.jl:398-422) for every train pair of the two handles."""
+    if work_cap <= 0:
+        work_cap = 256 // int(x.dims[0])
+    _lib.check(_lib.lib().ttn_hadamard_ttm(x.h, y.h, z.h, float(tol), int(min(rmax, 2 ** 62)), int(work_cap)))
+    return z
+
+
+# ---- host level (one train: upload, run, download) ----------------------------------------------------------------------
+def _swap_capacity(d: int, cap: int) -> List[int]:
+    """Uniform rank capacity: a swap SVD keeps min(n r_left, n r_right) directions (all of them when threshold == 0), which
+    can exceed the minimal-TT bound prod(dims[:k]) of the bond — the chain is not in minimal form in between."""
+    return [1] + [cap] * (d - 1) + [1]
+
+
+def hadamard_ttm(x: TTvector, y: TTvector, tol: float = 1.0e-14, rmax: int = 2 ** 62) -> TTvector:
+    assert tuple(x.ttv_dims) == tuple(y.ttv_dims), "Incompatible TT dimensions"
+    n = int(x.ttv_dims[0])
+    cap = 256 // n
+    dx, dy = DeviceTT.from_host(x), DeviceTT.from_host(y)
+    dz = DeviceTT(x.ttv_dims, _swap_capacity(x.N, cap))
+    hadamard_ttm_(dx, dy, dz, tol, rmax, cap)
+    compress_status(dz)
+    dz.max_ranks()
+    return dz.download(0)
+
+
+def reorder(x: TTvector, n_dims: int, bits_per_dim: int, new_ordering: str, threshold: float = 0.0) -> TTvector:
+    """reorder(q, new_ordering; threshold) (src/qtt_tools.jl:733-775) for the TTvector of a QTTvector with the given
+    metadata (currently in the OTHER ordering).  Returns the reordered TTvector."""
+    assert x.N == n_dims * bits_per_dim
+    n = int(x.ttv_dims[0])
+    dx = DeviceTT.from_host(x, cap_rks=_swap_capacity(x.N, 256 // n))
+    swap_sites_(dx, bubble_sort_swaps(reorder_perm(n_dims, bits_per_dim, new_ordering)), threshold)
+    compress_status(dx)
+    dx.max_ranks()
+    return dx.download(0)

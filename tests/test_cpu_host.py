@@ -142,3 +142,25 @@ def test_c_abi_argument_errors_without_gpu(T):
     out = (ctypes.c_int64 * 3)()
     assert L.ttn_r_and_d_to_rks(2, None, 3, None, 4, out) == T._lib.TTN_ERR_ARG
     assert b"bad argument" in L.ttn_last_error_string()
+
+
+# ---- site-swap chains: integer work of reorder is bit-exact with the oracle ----------------------------------
+def test_reorder_swap_lists_match_oracle():
+    import ttn_amd as T
+    from oracle import tt_oracle as O
+    for n_dims in range(1, 5):
+        for bits in range(1, 7):
+            for name, flag in (("interleaved", True), ("serial", False)):
+                perm = T.reorder_perm(n_dims, bits, name)
+                assert perm == O.reorder_perm(n_dims, bits, flag)
+                assert sorted(perm) == list(range(n_dims * bits))
+                sw = T.bubble_sort_swaps(perm)
+                assert sw == O.bubble_sort_swaps(perm)
+                # applying the swaps sorts the permutation
+                p = list(perm)
+                for k in sw:
+                    p[k - 1], p[k] = p[k], p[k - 1]
+                assert p == sorted(perm)
+    # the two orderings are inverse site maps
+    a, b = T.reorder_perm(3, 4, "interleaved"), T.reorder_perm(3, 4, "serial")
+    assert [b[a[i]] for i in range(12)] == list(range(12))

@@ -287,3 +287,37 @@ def test_rk4_step_vs_dense():
     K4 = Ad @ (ud + h * K3)
     ref = ud + h / 6 * (K1 + 2 * K2 + 2 * K3 + K4)
     assert np.linalg.norm(O.qtt_to_vector(sol) - ref) / np.linalg.norm(ref) < 1e-6
+
+
+# ---- hadamard_ttm / reorder ------------------------------------------------------------------------------
+def test_hadamard_ttm_known_answers():
+    """test/test_tt_operations.jl:72-99 — "Hadamard TTM algorithm vs naive", same inputs and tolerances."""
+    d = 8
+    xp = np.linspace(0, 1, 2 ** d)
+    A1, A2, A3 = O.qtt_exp(d), O.qtt_sin(d, lam=math.pi), O.qtt_cos(d, lam=math.pi)
+    A4 = O.qtt_polynom([0.0, 2.0, 3.0, -8.0, -5.0], d, a=0.0, b=1.0)
+    pol = 2 * xp + 3 * xp ** 2 - 8 * xp ** 3 - 5 * xp ** 4
+    assert np.allclose(O.qtt_to_vector(O.hadamard_ttm(A2, A3)), np.cos(math.pi ** 2 * xp) * np.sin(math.pi ** 2 * xp), atol=1e-10, rtol=0)
+    assert np.allclose(O.qtt_to_vector(O.hadamard_ttm(A1, A2)), np.exp(xp) * np.sin(math.pi ** 2 * xp), atol=1e-10, rtol=0)
+    assert np.allclose(O.qtt_to_vector(O.hadamard_ttm(A4, A2)), pol * np.sin(math.pi ** 2 * xp), atol=1e-4, rtol=0)
+    assert np.allclose(O.qtt_to_vector(O.hadamard_ttm(A4, A3)), pol * np.cos(math.pi ** 2 * xp), atol=1e-4, rtol=0)
+    for a, b in ((A2, A3), (A1, A2), (A4, A2), (A4, A3)):
+        h = O.hadamard(a, b)
+        assert O.euclidean_distance(O.hadamard_ttm(a, b), h) / O.norm(h) < 1e-5
+
+
+def test_reorder_round_trip_and_axis_permutation():
+    """test/test_qtt_multidim.jl:182-199, 488-518: reorder preserves the function values (here: the dense tensor with
+    permuted axes), round-trips, and preserves the norm."""
+    rng = np.random.default_rng(3)
+    for n_dims, bits in ((2, 3), (3, 3)):
+        N = n_dims * bits
+        x = O.rand_tt((2,) * N, 3, rng)
+        dense = O.ttv_to_tensor(x)
+        for thr in (0.0, 1e-14):
+            il = O.reorder(x, n_dims, bits, True, threshold=thr)
+            perm = O.reorder_perm(n_dims, bits, True)
+            assert np.max(np.abs(O.ttv_to_tensor(il) - np.transpose(dense, np.argsort(perm)))) < 1e-10
+            back = O.reorder(il, n_dims, bits, False, threshold=thr)
+            assert np.max(np.abs(O.ttv_to_tensor(back) - dense)) < 1e-10
+            assert abs(O.norm(il) - O.norm(x)) <= 1e-10 * O.norm(x)
