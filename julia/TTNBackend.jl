@@ -140,5 +140,11 @@ end
 #   ccall((:ttn_tt_core_export, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int64}), y, k, devbuf, devrks)   # -> ncclSend
 #   ccall((:ttn_tt_core_import, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int64}, Int64, Int64), y, k, devbuf, devrks, bl, br)
 # (k, k_first, k_last 1-based like _tt_bond_truncate!; devbuf / devrks are device pointers).
+#
+# Site-swap chains (INTEGRATION.md §2): hadamard_ttm and reorder run on handles,
+#   ccall((:ttn_hadamard_ttm, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int64), x, y, z, tol, rmax, work_cap)
+#   ccall((:ttn_swap_sites, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Float64), q, length(swaps), swaps, threshold)
+# with swaps = _bubble_sort_swaps(perm) exactly as reorder computes it (src/qtt_tools.jl:759); ttn_compress_status reports a
+# rank that outgrew its slot (-5) or a Jacobi SVD that hit its sweep limit (-9).
 
 end # module
