@@ -37,7 +37,7 @@ __all__ = [
     "sub", "div", "orthogonalize", "svdtrunc", "svdtrunc_shadowed", "tt_bond_truncate_",
     "tt_compress_", "copy_tt", "rk4_method", "euler_method",
     "ttm_swap_", "ttm_contract_", "hadamard_ttm", "swap_adjacent_sites", "bubble_sort_swaps", "reorder_perm",
-    "swap_sites_", "reorder",
+    "swap_sites_", "reorder", "swap_adjacent_sites_op", "reorder_op",
 ]
 
 
@@ -654,6 +654,30 @@ def reorder(x: TTvector, n_dims: int, bits_per_dim: int, to_interleaved: bool, t
     """reorder(q, new_ordering; threshold) (src/qtt_tools.jl:733-775) for a QTT vector given as its TTvector plus metadata."""
     y = copy_tt(x)
     return swap_sites_(y, bubble_sort_swaps(reorder_perm(n_dims, bits_per_dim, to_interleaved)), threshold=threshold)
+
+
+def swap_adjacent_sites_op(A: np.ndarray, B: np.ndarray, threshold: float = 0.0):
+    """_swap_adjacent_sites_op (src/qtt_tools.jl:852-885): operator cores (phys, phys, r_left, r_right)."""
+    d1, _, rl, _ = A.shape
+    d2, _, _, rr = B.shape
+    C = np.einsum("ijlm,pqmr->ijpqlr", A, B)        # C[i1, j1, i2, j2, l, r]
+    # permutedims(C, (3, 4, 5, 1, 2, 6)) -> (i2, j2, l, i1, j1, r); column-major reshape
+    M = np.reshape(C.transpose(2, 3, 4, 0, 1, 5), (d2 * d2 * rl, d1 * d1 * rr), order="F")
+    U, sv, Vt = sla.svd(M, full_matrices=False, lapack_driver="gesdd")
+    r_new = max(1, int(np.count_nonzero(sv > threshold * sv[0]))) if threshold > 0 else len(sv)
+    new_A = np.reshape(U[:, :r_new], (d2, d2, rl, r_new), order="F").copy()
+    SV = sv[:r_new, None] * Vt[:r_new, :]
+    new_B = np.reshape(SV, (r_new, d1, d1, rr), order="F").transpose(1, 2, 0, 3).copy()
+    return new_A, new_B
+
+
+def reorder_op(A: TToperator, n_dims: int, bits_per_dim: int, to_interleaved: bool, threshold: float = 0.0) -> TToperator:
+    """reorder(A::QTToperator, new_ordering; threshold) (src/qtt_tools.jl:894-932)."""
+    cores = [np.array(c) for c in A.tto_vec]
+    for k in bubble_sort_swaps(reorder_perm(n_dims, bits_per_dim, to_interleaved)):
+        cores[k - 1], cores[k] = swap_adjacent_sites_op(cores[k - 1], cores[k], threshold=threshold)
+    rks = [1] + [int(c.shape[3]) for c in cores]
+    return TToperator(A.N, cores, tuple(2 for _ in range(A.N)), rks, [0] * A.N)
 
 
 # --------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ from typing import List, Sequence
 
 from . import _lib
 from .device import DeviceTT, compress_status
-from .tt import TTvector, _i64
+from .tt import TToperator, TTvector, _i64
 
 
 def bubble_sort_swaps(perm: Sequence[int]) -> List[int]:
@@ -86,3 +86,22 @@ def reorder(x: TTvector, n_dims: int, bits_per_dim: int, new_ordering: str, thre
     compress_status(dx)
     dx.max_ranks()
     return dx.download(0)
+
+
+def reorder_op(A: TToperator, n_dims: int, bits_per_dim: int, new_ordering: str, threshold: float = 0.0) -> TToperator:
+    """reorder(A::QTToperator, new_ordering; threshold) (src/qtt_tools.jl:852-932).  An operator core (i, j, a, b) IS a vector
+    core with the physical index i + n*j in memory, and _swap_adjacent_sites_op is _swap_adjacent_sites on that index: the
+    operator rides the same kernel as a train with physical dimension n^2."""
+    import numpy as np
+    assert A.N == n_dims * bits_per_dim
+    n = int(A.tto_dims[0])
+    dims = tuple(n * n for _ in range(A.N))
+    vec = TTvector(A.N, [np.reshape(np.asfortranarray(c), (n * n, c.shape[2], c.shape[3]), order="F") for c in A.tto_vec],
+                   dims, list(A.tto_rks), [0] * A.N)
+    dx = DeviceTT.from_host(vec, cap_rks=_swap_capacity(A.N, 256 // (n * n)))
+    swap_sites_(dx, bubble_sort_swaps(reorder_perm(n_dims, bits_per_dim, new_ordering)), threshold)
+    compress_status(dx)
+    dx.max_ranks()
+    out = dx.download(0)
+    cores = [np.reshape(np.asfortranarray(c), (n, n, c.shape[1], c.shape[2]), order="F") for c in out.ttv_vec]
+    return TToperator(A.N, cores, tuple(A.tto_dims), list(out.ttv_rks), [0] * A.N)

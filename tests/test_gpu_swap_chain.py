@@ -199,3 +199,21 @@ def test_swap_sites_batch_and_errors(T):
     small = T.DeviceTT.from_host(to_product(xs[0]))          # capacity = current ranks: threshold 0 must grow a bond
     with pytest.raises(T.TTNError):
         T.qtt.swap_sites_(small, [4], 0.0)
+
+
+@pytest.mark.parametrize("n_dims,bits,R,seed", [(2, 3, 3, 0), (3, 2, 2, 1), (2, 4, 2, 2)])
+def test_reorder_op_vs_oracle(T, n_dims, bits, R, seed):
+    """reorder(A::QTToperator) (src/qtt_tools.jl:852-932): the operator rides the vector kernel with physical dimension 4."""
+    rng = np.random.default_rng(seed)
+    N = n_dims * bits
+    A = O.rand_tto((2,) * N, R, rng)
+    dense = O.tto_to_tensor(A)
+    inv = list(np.argsort(O.reorder_perm(n_dims, bits, True)))
+    for threshold in (0.0, 1e-13):
+        ref = O.reorder_op(A, n_dims, bits, True, threshold=threshold)
+        got = T.reorder_op(to_product(A), n_dims, bits, "interleaved", threshold=threshold)
+        assert list(got.tto_rks) == list(ref.tto_rks)
+        _close(O.tto_to_tensor(to_oracle(got)), np.transpose(dense, inv + [N + a for a in inv]), 1e-11)
+        if threshold > 0 or N <= 6:      # threshold 0 keeps every direction: at N = 8 the way back outgrows the rank capacity (64)
+            back = T.reorder_op(got, n_dims, bits, "serial", threshold=threshold)
+            _close(O.tto_to_tensor(to_oracle(back)), dense, 1e-11)

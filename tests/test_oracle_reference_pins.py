@@ -321,3 +321,19 @@ def test_reorder_round_trip_and_axis_permutation():
             back = O.reorder(il, n_dims, bits, False, threshold=thr)
             assert np.max(np.abs(O.ttv_to_tensor(back) - dense)) < 1e-10
             assert abs(O.norm(il) - O.norm(x)) <= 1e-10 * O.norm(x)
+
+
+def test_reorder_op_is_the_axis_permutation():
+    """test/test_qtt_multidim.jl:694-722 checks reorder(A::QTToperator) through A*v on function values; the same statement
+    on the dense operator: both index groups are permuted by reorder's site map, and the round trip is the identity."""
+    rng = np.random.default_rng(4)
+    n_dims, bits = 2, 3
+    N = n_dims * bits
+    A = O.rand_tto((2,) * N, 3, rng)
+    dense = O.tto_to_tensor(A)
+    inv = list(np.argsort(O.reorder_perm(n_dims, bits, True)))
+    for thr in (0.0, 1e-14):
+        B = O.reorder_op(A, n_dims, bits, True, threshold=thr)
+        assert np.max(np.abs(O.tto_to_tensor(B) - np.transpose(dense, inv + [N + a for a in inv]))) < 1e-10 * np.max(np.abs(dense))
+        C = O.reorder_op(B, n_dims, bits, False, threshold=thr)
+        assert np.max(np.abs(O.tto_to_tensor(C) - dense)) < 1e-10 * np.max(np.abs(dense))
