@@ -126,6 +126,12 @@ int ttn_tt_core_import(ttn_tt_t h, int64_t k, const double* dev_buf, const int64
 int ttn_hadamard_ttm(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z, double tol, int64_t rmax, int64_t work_cap);
 int ttn_swap_sites(ttn_tt_t x, int64_t nswaps, const int64_t* swaps, double threshold);
 
+/* z_b = ttv_decomp(tensor_b; index, tol) (src/tt_tools.jl:186-252): hierarchical SVD of `batch` dense tensors of shape
+ * z.dims (HOST memory, [batch][prod(dims)], column-major like a Julia Array), root at site `index` (1-based), singular values
+ * below `tol` discarded (absolute).  Ranks are bounded by the handle's capacity: a larger rank is reported by
+ * ttn_compress_status as TTN_ERR_CAPACITY.  Sets the orthogonality flags -1 / 0 / +1 like the reference.  Synchronises. */
+int ttn_ttv_decomp(ttn_tt_t z, const double* tensors, int64_t index, double tol);
+
 /* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);
 

@@ -37,7 +37,7 @@ __all__ = [
     "sub", "div", "orthogonalize", "svdtrunc", "svdtrunc_shadowed", "tt_bond_truncate_",
     "tt_compress_", "copy_tt", "rk4_method", "euler_method",
     "ttm_swap_", "ttm_contract_", "hadamard_ttm", "swap_adjacent_sites", "bubble_sort_swaps", "reorder_perm",
-    "swap_sites_", "reorder", "swap_adjacent_sites_op", "reorder_op",
+    "swap_sites_", "reorder", "swap_adjacent_sites_op", "reorder_op", "ttv_decomp",
 ]
 
 
@@ -678,6 +678,52 @@ def reorder_op(A: TToperator, n_dims: int, bits_per_dim: int, to_interleaved: bo
         cores[k - 1], cores[k] = swap_adjacent_sites_op(cores[k - 1], cores[k], threshold=threshold)
     rks = [1] + [int(c.shape[3]) for c in cores]
     return TToperator(A.N, cores, tuple(2 for _ in range(A.N)), rks, [0] * A.N)
+
+
+# --------------------------------------------------------------------------------------
+# ttv_decomp — src/tt_tools.jl:186-252 (hierarchical SVD, absolute threshold)
+# --------------------------------------------------------------------------------------
+def ttv_decomp(tensor: np.ndarray, index: int = 1, tol: float = 1.0e-12) -> TTvector:
+    """index is 1-based.  Left of the root the reference assigns ALL columns of u into a core sized by the truncated rank
+    (:206-208), which throws a DimensionMismatch in Julia when a singular value falls below tol there; this restatement
+    truncates u instead (the only consistent completion) — that corner is parity-unpinned."""
+    tensor = np.asarray(tensor, dtype=float)
+    dims = tuple(int(v) for v in tensor.shape)
+    d = len(dims)
+    ot = [-1] * d
+    ot[index - 1] = 0
+    for i in range(index, d):
+        ot[i] = 1
+    rks = [1] * (d + 1)
+    vec: list = [None] * d
+    cur = tensor
+    for i in range(1, index):                                    # :199-211
+        cur = np.reshape(cur, (rks[i - 1] * dims[i - 1], -1), order="F")
+        u, sv, vt = sla.svd(cur, full_matrices=False, lapack_driver="gesdd")
+        r = int(np.count_nonzero(sv >= tol))
+        rks[i] = r
+        core = np.zeros((dims[i - 1], rks[i - 1], r))
+        for x in range(dims[i - 1]):
+            core[x, :, :] = u[rks[i - 1] * x: rks[i - 1] * (x + 1), :r]
+        vec[i - 1] = core
+        cur = sv[:r, None] * vt[:r, :]
+    for i in range(d, index, -1):                                # :214-233
+        cur = np.reshape(cur, (-1, dims[i - 1] * rks[i]), order="F")
+        u, sv, vt = sla.svd(cur, full_matrices=False, lapack_driver="gesdd")
+        r = int(np.count_nonzero(sv >= tol))
+        rks[i - 1] = r
+        core = np.zeros((dims[i - 1], r, rks[i]))
+        for x in range(dims[i - 1]):
+            cols = [dims[i - 1] * be + x for be in range(rks[i])]
+            core[x, :, :] = vt[:r, cols]
+        vec[i - 1] = core
+        cur = u[:, :r] * sv[None, :r]
+    cur = np.reshape(cur, (dims[index - 1] * rks[index - 1], -1), order="F")   # :236-245
+    core = np.zeros((dims[index - 1], rks[index - 1], rks[index]))
+    for x in range(dims[index - 1]):
+        core[x, :, :] = cur[rks[index - 1] * x: rks[index - 1] * (x + 1), :rks[index]]
+    vec[index - 1] = core
+    return TTvector(d, vec, dims, rks, ot)
 
 
 # --------------------------------------------------------------------------------------

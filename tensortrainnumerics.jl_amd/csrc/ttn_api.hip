@@ -4,6 +4,7 @@
 #include "ttn_stream_kernels.h"
 #include "ttn_dense_kernels.h"
 #include "ttn_ortho_kernels.h"
+#include "ttn_hsvd_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -144,6 +145,8 @@ int ttn_init(int device) {
     // the compress / orthogonalize kernels use more than the default 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compress), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(COMPRESS_LDS_BYTES)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ttv_decomp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_swap_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_orthogonalize), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -894,12 +897,84 @@ int ttn_swap_sites(ttn_tt_t x, int64_t nswaps, const int64_t* swaps, double thre
     return TTN_OK;
 }
 
+// ---- ttv_decomp: dense tensors -> trains ----------------------------------------------------------------
+int ttn_ttv_decomp(ttn_tt_t z, const double* tensors, int64_t index, double tol) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!z || !tensors) return fail(TTN_ERR_ARG, "null argument");
+    const int d = z->d;
+    if (index < 1 || index > d) return fail(TTN_ERR_ARG, "index must be in 1:d");
+    long long total = 1, nmax = 1, nmin = 1LL << 40;
+    for (int k = 0; k < d; ++k) {
+        total *= z->dims[k];
+        nmax = std::max<long long>(nmax, z->dims[k]);
+        nmin = std::min<long long>(nmin, z->dims[k]);
+        if (total > (1LL << 27)) return fail(TTN_ERR_UNSUPPORTED, "ttn_ttv_decomp: more than 2^27 entries per tensor");
+    }
+    // worst-case short / long sides of the unfoldings, with the ranks bounded by the handle's capacity
+    std::vector<int64_t> bnd(d + 1, 1);
+    long long pmax = 1, qmax = 1;
+    {
+        long long len = total, rl = 1;
+        for (int i = 0; i < index - 1; ++i) {
+            const long long a = rl * z->dims[i], bc = len / a;
+            pmax = std::max(pmax, std::min(a, bc)); qmax = std::max(qmax, std::max(a, bc));
+            rl = std::min<long long>(std::min(a, bc), z->cap[i + 1]);
+            bnd[i + 1] = rl; len = rl * bc;
+        }
+        long long rr = 1;
+        for (int i = d - 1; i > index - 1; --i) {
+            const long long a = z->dims[i] * rr, rows = len / a;
+            pmax = std::max(pmax, std::min(a, rows)); qmax = std::max(qmax, std::max(a, rows));
+            rr = std::min<long long>(std::min(a, rows), z->cap[i]);
+            bnd[i] = rr; len = rows * rr;
+        }
+    }
+    if (pmax > 4096) return fail(TTN_ERR_UNSUPPORTED, "ttn_ttv_decomp: an unfolding has a short side above 4096 (lower the handle's rank capacity)");
+    const long long per_scr = QR_NB * qmax + pmax * QR_NB + 2 * pmax * pmax + 4 * pmax + 64;
+    const long long per_train = 3 * total + per_scr;
+    const int batch = z->batch;
+    int rc = ensure_scratch(sizeof(double) * ((size_t)per_train * batch + (size_t)total * batch));
+    if (rc) return rc;
+    rc = ensure_batch_bufs(batch);
+    if (rc) return rc;
+    double* base = (double*)g_scratch;
+    double* d_in = base + (size_t)per_train * batch;
+    HIPCHK(hipMemcpyAsync(d_in, tensors, sizeof(double) * (size_t)total * batch, hipMemcpyHostToDevice, g_stream));
+    HsvdArgs H;
+    memset(&H, 0, sizeof(H));
+    CompressArgs& P = H.C;
+    P.tt = z->dev();
+    P.max_bond = (int64_t)1 << 62;
+    P.sweeps = 1;
+    P.scratch = base + 3 * total;                          // per train: [cur0 | cur1 | M2 | LQ / Jacobi scratch]
+    P.scratch_stride = per_train;
+    P.pmax = (int)pmax; P.qmax = (int)qmax;
+    P.status = g_status;
+    P.sweep_stats = g_status + batch;
+    { const char* e = getenv("TTN_JTOL"); P.jtol_mult = e ? atof(e) : 1.0; }
+    { const char* e = getenv("TTN_JNEG"); P.jneg_mult = e ? atof(e) : 1.0; }
+    H.tensors = d_in;
+    H.total = total;
+    H.index = (int)index - 1;
+    H.tol = tol;
+    H.work = base;
+    H.work_stride = per_train;
+    hipLaunchKernelGGL(k_ttv_decomp, dim3(batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, H);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g_stream));                // `tensors` is caller memory: do not keep it in flight
+    z->bound = bnd;
+    for (int b = 0; b < batch; ++b)
+        for (int k = 0; k < d; ++k) z->ot[(size_t)b * d + k] = (k < index - 1) ? -1 : (k == index - 1 ? 0 : 1);     // tt_tools.jl:191-198
+    return TTN_OK;
+}
+
 // status of the last dense kernel (synchronises): returns TTN_ERR_NO_CONVERGENCE if any train failed
 static int check_status(int batch) {
     std::vector<int> st(batch);
     HIPCHK(hipMemcpyAsync(st.data(), g_status, sizeof(int) * batch, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
-    for (int b = 0; b < batch; ++b) if (st[b] == 2) return fail(TTN_ERR_CAPACITY, "a rank grew beyond the capacity of its slot (site-swap chain)");
+    for (int b = 0; b < batch; ++b) if (st[b] == 2) return fail(TTN_ERR_CAPACITY, "a rank grew beyond the rank capacity of its handle / working slot (site-swap chain or ttv_decomp)");
     for (int b = 0; b < batch; ++b) if (st[b]) return fail(TTN_ERR_NO_CONVERGENCE, "Jacobi SVD hit its sweep limit");
     return TTN_OK;
 }

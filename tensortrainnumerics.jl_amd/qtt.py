@@ -105,3 +105,32 @@ def reorder_op(A: TToperator, n_dims: int, bits_per_dim: int, new_ordering: str,
     out = dx.download(0)
     cores = [np.reshape(np.asfortranarray(c), (n, n, c.shape[1], c.shape[2]), order="F") for c in out.ttv_vec]
     return TToperator(A.N, cores, tuple(A.tto_dims), list(out.ttv_rks), [0] * A.N)
+
+
+# ---- ttv_decomp ---------------------------------------------------------------------------------------------------------
+def ttv_decomp_(z: DeviceTT, tensors, index: int = 1, tol: float = 1.0e-12) -> DeviceTT:
+    """z_b = ttv_decomp(tensors[b]; index, tol) (src/tt_tools.jl:186-252) for a batch of dense tensors of shape z.dims."""
+    import numpy as np
+    arr = np.asarray(tensors, dtype=np.float64)
+    assert arr.shape == (z.batch,) + tuple(z.dims), "tensors must have shape (batch, *dims)"
+    flat = np.ascontiguousarray(np.stack([np.ravel(arr[b], order="F") for b in range(z.batch)]))
+    _lib.check(_lib.lib().ttn_ttv_decomp(z.h, flat.ctypes.data_as(C.c_void_p), int(index), float(tol)))
+    return z
+
+
+def ttv_decomp(tensor, index: int = 1, tol: float = 1.0e-12, rank_cap: int = 1024) -> TTvector:
+    """Host-level form for one tensor: capacity = the exact-rank bounds min(prod(dims[:k]), prod(dims[k:]), rank_cap)."""
+    import numpy as np
+    t = np.asarray(tensor, dtype=np.float64)
+    dims = tuple(int(v) for v in t.shape)
+    d = len(dims)
+    cap = [1] * (d + 1)
+    for k in range(1, d):
+        left = int(np.prod(dims[:k], dtype=object))
+        right = int(np.prod(dims[k:], dtype=object))
+        cap[k] = max(1, min(left, right, rank_cap))
+    z = DeviceTT(dims, cap)
+    ttv_decomp_(z, t[None, ...], index, tol)
+    compress_status(z)
+    z.max_ranks()
+    return z.download(0)

@@ -337,3 +337,27 @@ def test_reorder_op_is_the_axis_permutation():
         assert np.max(np.abs(O.tto_to_tensor(B) - np.transpose(dense, inv + [N + a for a in inv]))) < 1e-10 * np.max(np.abs(dense))
         C = O.reorder_op(B, n_dims, bits, False, threshold=thr)
         assert np.max(np.abs(O.tto_to_tensor(C) - dense)) < 1e-10 * np.max(np.abs(dense))
+
+
+# ---- ttv_decomp ----------------------------------------------------------------------------------------------
+def test_ttv_decomp_reference_cases():
+    """test/test_tt_tools.jl:319-322 (index = 2: ot == [-1, 0, 1], reconstruction 1e-10), :1023-1028 (Bell state: the
+    entanglement spectrum of the one bond is (1/2, 1/2))."""
+    rng = np.random.default_rng(0)
+    t = rng.standard_normal((2, 3, 2))
+    tt = O.ttv_decomp(t, index=2)
+    assert tt.ttv_ot == [-1, 0, 1]
+    assert np.allclose(O.ttv_to_tensor(tt), t, atol=1e-10, rtol=0)
+    bell = np.zeros((2, 2))
+    bell[0, 0] = bell[1, 1] = 1 / math.sqrt(2)
+    bt = O.ttv_decomp(bell)
+    assert bt.ttv_rks == [1, 2, 1]
+    sv = np.linalg.svd(bt.ttv_vec[0][:, 0, :], compute_uv=False)          # root core carries the Schmidt values
+    assert np.allclose(sv ** 2, [0.5, 0.5])
+    # exact-rank input: ranks are recovered, the gauge is as the docstring of the reference states
+    x = O.rand_tt((2,) * 9, 3, rng)
+    dense = O.ttv_to_tensor(x)
+    for index in (1, 5, 9):
+        tt = O.ttv_decomp(dense, index=index, tol=1e-10 * np.max(np.abs(dense)))
+        assert tt.ttv_rks == x.ttv_rks
+        assert np.max(np.abs(O.ttv_to_tensor(tt) - dense)) < 1e-12 * np.max(np.abs(dense))
