@@ -39,6 +39,7 @@ extern "C" {
 #define TTN_ERR_NOT_INIT      -7   /* ttn_init was not called (or failed)                           */
 #define TTN_ERR_UNSUPPORTED   -8   /* shape outside what the kernels support (stated in DESIGN.md)  */
 #define TTN_ERR_NO_CONVERGENCE -9  /* Jacobi SVD hit its sweep limit on some bond                   */
+#define TTN_ERR_SINGULAR      -10  /* als_linsolve: a local system K is singular (LAPACK's SingularException)  */
 
 /* ---- library lifetime ------------------------------------------------------------------------ */
 int         ttn_init(int device);            /* binds to HIP device `device`, creates the stream   */
@@ -131,6 +132,13 @@ int ttn_swap_sites(ttn_tt_t x, int64_t nswaps, const int64_t* swaps, double thre
  * below `tol` discarded (absolute).  Ranks are bounded by the handle's capacity: a larger rank is reported by
  * ttn_compress_status as TTN_ERR_CAPACITY.  Sets the orthogonality flags -1 / 0 / +1 like the reference.  Synchronises. */
 int ttn_ttv_decomp(ttn_tt_t z, const double* tensors, int64_t index, double tol);
+
+/* --- als_linsolve(A, b, tt_start; sweep_count) (src/solvers/als.jl:161-222): x = the ALS iterate after
+ * sweep_count half sweeps, for every train of the batch (one operator, `batch` right-hand sides b and start trains x0).
+ * x receives orthogonalize(x0) first (als.jl:174) and keeps x0's ranks (als.jl:177); the local systems are assembled
+ * densely and solved by LU with partial pivoting like the reference's `K \ Pb` (als.jl:58-70).  All trains of x0 must carry
+ * the same ranks; n r_{i-1} r_i <= 2048.  ttn_compress_status(x) reports a singular local system (TTN_ERR_SINGULAR). */
+int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t sweep_count);
 
 /* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);

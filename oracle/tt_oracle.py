@@ -38,6 +38,7 @@ __all__ = [
     "tt_compress_", "copy_tt", "rk4_method", "euler_method",
     "ttm_swap_", "ttm_contract_", "hadamard_ttm", "swap_adjacent_sites", "bubble_sort_swaps", "reorder_perm",
     "swap_sites_", "reorder", "swap_adjacent_sites_op", "reorder_op", "ttv_decomp",
+    "als_linsolve", "tto_add", "tto_scale",
 ]
 
 
@@ -724,6 +725,119 @@ def ttv_decomp(tensor: np.ndarray, index: int = 1, tol: float = 1.0e-12) -> TTve
         core[x, :, :] = cur[rks[index - 1] * x: rks[index - 1] * (x + 1), :rks[index]]
     vec[index - 1] = core
     return TTvector(d, vec, dims, rks, ot)
+
+
+# --------------------------------------------------------------------------------------
+# TToperator + and scalar * (inputs of the ALS tests) — src/tt_operations.jl:71-96, :268-281
+# --------------------------------------------------------------------------------------
+def tto_add(A: TToperator, B: TToperator) -> TToperator:
+    d = A.N
+    rks = [a + b for a, b in zip(A.tto_rks, B.tto_rks)]
+    rks[0] = rks[d] = 1
+    vec = []
+    for k in range(d):
+        n = A.tto_dims[k]
+        core = np.zeros((n, n, rks[k], rks[k + 1]))
+        a, b = A.tto_vec[k], B.tto_vec[k]
+        if k == 0:
+            core[:, :, 0, :A.tto_rks[1]] = a[:, :, 0, :]
+            core[:, :, 0, A.tto_rks[1]:] = b[:, :, 0, :]
+        elif k == d - 1:
+            core[:, :, :A.tto_rks[k], 0] = a[:, :, :, 0]
+            core[:, :, A.tto_rks[k]:, 0] = b[:, :, :, 0]
+        else:
+            core[:, :, :A.tto_rks[k], :A.tto_rks[k + 1]] = a
+            core[:, :, A.tto_rks[k]:, A.tto_rks[k + 1]:] = b
+        vec.append(core)
+    return TToperator(d, vec, tuple(A.tto_dims), rks, [0] * d)
+
+
+def tto_scale(a: float, A: TToperator) -> TToperator:
+    vec = [np.array(c) for c in A.tto_vec]
+    vec[0] = a * vec[0]
+    return TToperator(A.N, vec, tuple(A.tto_dims), list(A.tto_rks), list(A.tto_ot))
+
+
+# --------------------------------------------------------------------------------------
+# als_linsolve — src/solvers/als.jl:9-70 (environments, Ksolve), :102-135 (core moves), :161-222
+# --------------------------------------------------------------------------------------
+def _als_update_H(x, A, Hi):
+    # Him[a, al, be] = conj(x)[j, al, ph] * Hi[z, ph, ch] * x[k, be, ch] * A[j, k, a, z]      (als.jl:23-26)
+    return np.einsum("jap,zpc,kbc,jkyz->yab", x, Hi, x, A, optimize=True)
+
+
+def _als_update_Hb(x, b, Hbi):
+    # H_bim[al, be] = H_bi[ph, ch] * b[i, be, ch] * conj(x)[i, al, ph]                        (als.jl:42-45)
+    return np.einsum("pc,ibc,iap->ab", Hbi, b, x, optimize=True)
+
+
+def _als_update_G(x, A, Gi):
+    # Gip[j, al, k, be, J] = conj(x)[l, ph, al] * (Gi[l, ph, m, ch, L] * x[m, ch, be]) * A[j, k, L, J]   (als.jl:47-50)
+    return np.einsum("lpa,lpmcL,mcb,jkLJ->jakbJ", x, Gi, x, A, optimize=True)
+
+
+def _als_update_Gb(x, b, Gbi):
+    # G_bip[i, al, be] = b[i, ph, be] * G_bi[j, ch, ph] * conj(x)[j, ch, al]                   (als.jl:52-55)
+    return np.einsum("ipb,jcp,jca->iab", b, Gbi, x, optimize=True)
+
+
+def _als_ksolve(Gi, Gbi, Hi, Hbi):
+    n, rim, ri = Gi.shape[0], Gi.shape[1], Hi.shape[1]
+    N = n * rim * ri
+    # K[(a,b,c),(d,e,f)] = Gi[a,b,d,e,z] * Hi[z,c,f], column-major multi-indices (als.jl:58-63)
+    K6 = np.einsum("abdez,zcf->abcdef", Gi, Hi)
+    K = np.reshape(K6, (N, N), order="F")
+    Pb = np.einsum("iab,cb->iac", Gbi, Hbi)                      # (n, rim, ri)  (als.jl:68)
+    V = np.linalg.solve(K, np.reshape(Pb, N, order="F"))         # K \ Pb[:]
+    return np.reshape(V, (n, rim, ri), order="F")
+
+
+def als_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, sweep_count: int = 2) -> TTvector:
+    """als_linsolve(A, b, tt_start; sweep_count) (src/solvers/als.jl:161-222), dense local solves (it_solver is ignored
+    by the reference, :161,203)."""
+    d = A.N
+    x = orthogonalize(tt_start)                                  # :174
+    dims = tuple(tt_start.ttv_dims)
+    rks = list(tt_start.ttv_rks)                                 # fixed ranks (:177)
+    G = [None] * d
+    Gb = [None] * d
+    G[0] = np.reshape(A.tto_vec[0][:, :, 0, :], (dims[0], 1, dims[0], 1, -1))        # :188
+    Gb[0] = np.reshape(b.ttv_vec[0], (dims[0], 1, -1))                                # :189
+    H = [None] * d
+    Hb = [None] * d
+    H[d - 1] = np.ones((1, 1, 1))
+    Hb[d - 1] = np.ones((1, 1))
+    for i in range(d - 1, 0, -1):                                # init_H / init_Hb (:9-21, :28-40)
+        H[i - 1] = _als_update_H(x.ttv_vec[i], A.tto_vec[i], H[i])
+        Hb[i - 1] = _als_update_Hb(x.ttv_vec[i], b.ttv_vec[i], Hb[i])
+    nsweeps = 0
+    while nsweeps < sweep_count:
+        nsweeps += 1
+        for i in range(d - 1):                                   # first half sweep (:199-207), i 0-based
+            V = _als_ksolve(G[i], Gb[i], H[i], Hb[i])
+            n, rim, ri = dims[i], rks[i], rks[i + 1]
+            Q, R = np.linalg.qr(np.reshape(V, (n * rim, ri), order="F"))             # right_core_move (:122-135)
+            x.ttv_vec[i] = np.reshape(Q[:, :ri], (n, rim, ri), order="F")
+            x.ttv_ot[i] = -1
+            x.ttv_vec[i + 1] = np.einsum("bz,azc->abc", R[:ri, :], x.ttv_vec[i + 1])
+            x.ttv_ot[i + 1] = 0
+            G[i + 1] = _als_update_G(x.ttv_vec[i], A.tto_vec[i + 1], G[i])
+            Gb[i + 1] = _als_update_Gb(x.ttv_vec[i], b.ttv_vec[i + 1], Gb[i])
+        if nsweeps == sweep_count:
+            return x
+        nsweeps += 1
+        for i in range(d - 1, 0, -1):                            # second half sweep (:213-219)
+            V = _als_ksolve(G[i], Gb[i], H[i], Hb[i])
+            n, rim, ri = dims[i], rks[i], rks[i + 1]
+            M = np.reshape(np.transpose(V, (0, 2, 1)), (n * ri, rim), order="F")     # left_core_move (:102-120)
+            Q, R = np.linalg.qr(M)
+            x.ttv_vec[i] = np.transpose(np.reshape(Q[:, :rim], (n, ri, rim), order="F"), (0, 2, 1)).copy()
+            x.ttv_ot[i] = 1
+            x.ttv_vec[i - 1] = np.einsum("abz,cz->abc", x.ttv_vec[i - 1], R[:rim, :])
+            x.ttv_ot[i - 1] = 0
+            H[i - 1] = _als_update_H(x.ttv_vec[i], A.tto_vec[i], H[i])
+            Hb[i - 1] = _als_update_Hb(x.ttv_vec[i], b.ttv_vec[i], Hb[i])
+    return x
 
 
 # --------------------------------------------------------------------------------------

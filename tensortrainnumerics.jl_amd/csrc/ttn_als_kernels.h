@@ -1,0 +1,323 @@
+// ttn_als_kernels.h — als_linsolve (src/solvers/als.jl:161-222) for a batch of independent right-hand sides / start trains and
+// one operator: one workgroup owns one train for the whole solve (the half sweeps are sequential along the chain, like
+// tt_compress!).  Ranks are FIXED by the start train (als.jl:177), so every shape below is known on the host.
+//   environments   G_i (n, r_{i-1}, n, r_{i-1}, R_i), Gb_i (n, r_{i-1}, rb_i), H_i (R_i, r_i, r_i), Hb_i (r_i, rb_i)   (als.jl:9-55)
+//   local system   K[(a,b,c),(d,e,f)] = sum_z G_i[a,b,d,e,z] H_i[z,c,f] ;  Pb = Gb_i Hb_i' ;  V = K \ Pb               (als.jl:58-70)
+//   core moves     thin QR of V, R pushed into the neighbour                                                              (als.jl:102-135)
+// The reference assembles K densely and calls LAPACK's LU (`K \ b`; its it_solver keyword is ignored, :161,203): the device
+// does the same — dense K in global memory, right-looking LU with partial pivoting by the whole workgroup — so results agree
+// to rounding * cond(K).  The contractions are staged exactly as the reference's @tensoropt orders suggest (three small stages
+// each); at ALS sizes they are latency-, not flop-bound, and run on the VALU.  Local sizes n*r*r up to 2048 are supported.
+#pragma once
+#include "ttn_ortho_kernels.h"
+
+struct AlsArgs {
+    TTODev A;
+    TTDev b, x;
+    int sweep_count;
+    double* scratch;
+    long long scratch_stride;
+    const long long* off;        // device [4][d]: offsets of G_i, Gb_i, H_i, Hb_i in the per-train scratch
+    long long offK, offPb, offT1, offT2, offTm, offQb, offRb, offVb, offWb, offTst;
+    int mmax, rmax;
+    int* status;                 // [batch]: 0 ok, 3 singular local system, 4 ranks differ from the handle's bound
+    const long long* rfix;       // device [d+1]: the fixed ranks of x
+};
+
+// out-of-line helper: dense solve K v = rhs (in place, v overwrites rhs); K is N x N column-major (destroyed).
+// Right-looking LU with partial pivoting (first maximal |entry| like LAPACK's idamax), forward elimination applied to
+// the right-hand side on the fly, then back substitution.  Returns 0, or 1 if a pivot is exactly zero.
+__device__ __noinline__ int wg_lu_solve(int N, double* K, double* rhs, double* red, int* iflag) {
+    N = uni32(N); K = unip(K); rhs = unip(rhs); red = unip(red); iflag = unip(iflag);
+    const int tid = threadIdx.x;
+    for (int k = 0; k < N; ++k) {
+        double* colk = K + (long long)k * N;
+        double vm = 0.0;
+        for (int i = k + tid; i < N; i += TTN_WG) vm = fmax(vm, fabs(colk[i]));
+        if (tid == 0) iflag[0] = N;
+        vm = unif64(wg_max(vm, red));                       // barriers inside: iflag[0] is visible after it
+        if (!(vm > 0.0)) return 1;
+        for (int i = k + tid; i < N; i += TTN_WG) if (fabs(colk[i]) == vm) atomicMin(&iflag[0], i);
+        __syncthreads();
+        const int pv = uni32(iflag[0]);
+        __syncthreads();
+        if (pv != k) {
+            for (int j = tid; j < N; j += TTN_WG) { const double t = K[(long long)j * N + k]; K[(long long)j * N + k] = K[(long long)j * N + pv]; K[(long long)j * N + pv] = t; }
+            if (tid == 0) { const double t = rhs[k]; rhs[k] = rhs[pv]; rhs[pv] = t; }
+            __syncthreads();
+        }
+        const double piv = colk[k];
+        for (int i = k + 1 + tid; i < N; i += TTN_WG) colk[i] = colk[i] / piv;
+        __syncthreads();
+        const int m = N - k - 1;
+        // trailing update: K[i, j] -= l_i * K[k, j]; i fastest (coalesced)
+        for (long long e = tid; e < (long long)m * m; e += TTN_WG) {
+            const int i = k + 1 + (int)(e % m), j = k + 1 + (int)(e / m);
+            K[(long long)j * N + i] = fma(-colk[i], K[(long long)j * N + k], K[(long long)j * N + i]);
+        }
+        const double rk = rhs[k];
+        __syncthreads();
+        for (int i = k + 1 + tid; i < N; i += TTN_WG) rhs[i] = fma(-colk[i], rk, rhs[i]);
+        __syncthreads();
+    }
+    for (int k = N - 1; k >= 0; --k) {
+        const double* colk = K + (long long)k * N;
+        const double xk = rhs[k] / colk[k];
+        __syncthreads();
+        if (tid == 0) rhs[k] = xk;
+        for (int i = tid; i < k; i += TTN_WG) rhs[i] = fma(-colk[i], xk, rhs[i]);
+        __syncthreads();
+    }
+    return 0;
+}
+
+struct AlsSite { int n, rl, rr, Rl, Rr, bl, br; };
+
+__global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int d = P.x.d;
+    double* scr = P.scratch + (long long)b * P.scratch_stride;
+    double* red = lds + GEMM_LDS_TOTAL;
+    int* iflag = reinterpret_cast<int*>(red + 32 + 2 * QR_NB * QR_NB + QR_NB + 8);
+    OrthoWork W;
+    W.Vb = scr + P.offVb; W.Wb = scr + P.offWb; W.Tst = scr + P.offTst;
+    W.red = red; W.Ts = red + 32; W.Ss = W.Ts + QR_NB * QR_NB; W.taus = W.Ss + QR_NB * QR_NB;
+    double* K = scr + P.offK;
+    double* Pb = scr + P.offPb;
+    double* T1 = scr + P.offT1;
+    double* T2 = scr + P.offT2;
+    double* Tm = scr + P.offTm;
+    double* Qb = scr + P.offQb;
+    double* Rb = scr + P.offRb;
+    if (tid == 0) P.status[b] = 0;
+    // the ranks are fixed (als.jl:177): every train must carry exactly the handle's ranks
+    {
+        const long long* xr = P.x.rks + (long long)b * (d + 1);
+        bool bad = false;
+        for (int k = 0; k <= d; ++k) bad |= (xr[k] != P.rfix[k]);
+        if (bad) { if (tid == 0) P.status[b] = 4; return; }
+    }
+    const long long* br_ = P.b.rks + (long long)b * (d + 1);
+#define XC(i) (P.x.data + (long long)b * P.x.stride + P.x.off[i])
+#define BC(i) (P.b.data + (long long)b * P.b.stride + P.b.off[i])
+#define AC(i) (P.A.data + P.A.off[i])
+#define GP(i) (scr + P.off[i])
+#define GBP(i) (scr + P.off[d + (i)])
+#define HP(i) (scr + P.off[2 * d + (i)])
+#define HBP(i) (scr + P.off[3 * d + (i)])
+#define SITE(i) AlsSite{uni32(P.x.dims[i]), uni32((int)P.rfix[i]), uni32((int)P.rfix[(i) + 1]), uni32((int)P.A.rks[i]), uni32((int)P.A.rks[(i) + 1]), \
+                        uni32((int)br_[i]), uni32((int)br_[(i) + 1])}
+#define WG_FOR(total) for (long long e_ = tid; e_ < (long long)(total); e_ += TTN_WG)
+
+    // H_{i-1} from site i (als.jl:23-26) and Hb_{i-1} (als.jl:42-45)
+    auto update_H = [&](int i) {
+        const AlsSite s = SITE(i);
+        const double *x = XC(i), *A = AC(i), *Hi = HP(i), *Hbi = HBP(i), *bb = BC(i);
+        double *Ho = HP(i - 1), *Hbo = HBP(i - 1);
+        // T1[z, ph, k, be] = sum_ch H[z, ph, ch] x[k, be, ch]
+        WG_FOR((long long)s.Rr * s.rr * s.n * s.rl) {
+            long long t = e_; const int z = t % s.Rr; t /= s.Rr; const int ph = t % s.rr; t /= s.rr; const int k = t % s.n; const int be = (int)(t / s.n);
+            double a = 0.0;
+            for (int ch = 0; ch < s.rr; ++ch) a = fma(Hi[z + s.Rr * (ph + (long long)s.rr * ch)], x[k + s.n * (be + (long long)s.rl * ch)], a);
+            T1[e_] = a;
+        }
+        __syncthreads();
+        // T2[j, ph, a, be] = sum_{z, k} A[j, k, a, z] T1[z, ph, k, be]
+        WG_FOR((long long)s.n * s.rr * s.Rl * s.rl) {
+            long long t = e_; const int j = t % s.n; t /= s.n; const int ph = t % s.rr; t /= s.rr; const int a_ = t % s.Rl; const int be = (int)(t / s.Rl);
+            double a = 0.0;
+            for (int z = 0; z < s.Rr; ++z)
+                for (int k = 0; k < s.n; ++k)
+                    a = fma(A[j + s.n * (k + s.n * (a_ + (long long)s.Rl * z))], T1[z + s.Rr * (ph + (long long)s.rr * (k + (long long)s.n * be))], a);
+            T2[e_] = a;
+        }
+        __syncthreads();
+        // H_{i-1}[a, al, be] = sum_{j, ph} x[j, al, ph] T2[j, ph, a, be]
+        WG_FOR((long long)s.Rl * s.rl * s.rl) {
+            long long t = e_; const int a_ = t % s.Rl; t /= s.Rl; const int al = t % s.rl; const int be = (int)(t / s.rl);
+            double a = 0.0;
+            for (int ph = 0; ph < s.rr; ++ph)
+                for (int j = 0; j < s.n; ++j)
+                    a = fma(x[j + s.n * (al + (long long)s.rl * ph)], T2[j + s.n * (ph + (long long)s.rr * (a_ + (long long)s.Rl * be))], a);
+            Ho[e_] = a;
+        }
+        __syncthreads();
+        // Hb: T1[ph, i, be] = sum_ch Hb[ph, ch] b[i, be, ch] ; Hb_{i-1}[al, be] = sum_{i, ph} x[i, al, ph] T1[ph, i, be]
+        WG_FOR((long long)s.rr * s.n * s.bl) {
+            long long t = e_; const int ph = t % s.rr; t /= s.rr; const int ii = t % s.n; const int be = (int)(t / s.n);
+            double a = 0.0;
+            for (int ch = 0; ch < s.br; ++ch) a = fma(Hbi[ph + (long long)s.rr * ch], bb[ii + s.n * (be + (long long)s.bl * ch)], a);
+            T1[e_] = a;
+        }
+        __syncthreads();
+        WG_FOR((long long)s.rl * s.bl) {
+            const int al = (int)(e_ % s.rl), be = (int)(e_ / s.rl);
+            double a = 0.0;
+            for (int ph = 0; ph < s.rr; ++ph)
+                for (int ii = 0; ii < s.n; ++ii)
+                    a = fma(x[ii + s.n * (al + (long long)s.rl * ph)], T1[ph + s.rr * (ii + (long long)s.n * be)], a);
+            Hbo[e_] = a;
+        }
+        __syncthreads();
+    };
+    // G_{i+1}, Gb_{i+1} from site i (als.jl:47-55)
+    auto update_G = [&](int i) {
+        const AlsSite s = SITE(i);
+        const AlsSite s2 = SITE(i + 1);
+        const double *x = XC(i), *A2 = AC(i + 1), *Gi = GP(i), *Gbi = GBP(i), *b2 = BC(i + 1);
+        double *Go = GP(i + 1), *Gbo = GBP(i + 1);
+        // T1[l, ph, be, L] = sum_{m, ch} Gi[l, ph, m, ch, L] x[m, ch, be]
+        WG_FOR((long long)s.n * s.rl * s.rr * s.Rr) {
+            long long t = e_; const int l = t % s.n; t /= s.n; const int ph = t % s.rl; t /= s.rl; const int be = t % s.rr; const int L = (int)(t / s.rr);
+            double a = 0.0;
+            for (int ch = 0; ch < s.rl; ++ch)
+                for (int m = 0; m < s.n; ++m)
+                    a = fma(Gi[l + s.n * (ph + (long long)s.rl * (m + (long long)s.n * (ch + (long long)s.rl * L)))], x[m + s.n * (ch + (long long)s.rl * be)], a);
+            T1[e_] = a;
+        }
+        __syncthreads();
+        // T2[al, be, L] = sum_{l, ph} x[l, ph, al] T1[l, ph, be, L]
+        WG_FOR((long long)s.rr * s.rr * s.Rr) {
+            long long t = e_; const int al = t % s.rr; t /= s.rr; const int be = t % s.rr; const int L = (int)(t / s.rr);
+            double a = 0.0;
+            for (int ph = 0; ph < s.rl; ++ph)
+                for (int l = 0; l < s.n; ++l)
+                    a = fma(x[l + s.n * (ph + (long long)s.rl * al)], T1[l + s.n * (ph + (long long)s.rl * (be + (long long)s.rr * L))], a);
+            T2[e_] = a;
+        }
+        __syncthreads();
+        // G_{i+1}[j, al, k, be, J] = sum_L T2[al, be, L] A2[j, k, L, J]
+        WG_FOR((long long)s2.n * s.rr * s2.n * s.rr * s2.Rr) {
+            long long t = e_; const int j = t % s2.n; t /= s2.n; const int al = t % s.rr; t /= s.rr; const int k = t % s2.n; t /= s2.n; const int be = t % s.rr; const int J = (int)(t / s.rr);
+            double a = 0.0;
+            for (int L = 0; L < s.Rr; ++L)
+                a = fma(T2[al + s.rr * (be + (long long)s.rr * L)], A2[j + s2.n * (k + s2.n * (L + (long long)s2.Rl * J))], a);
+            Go[e_] = a;
+        }
+        __syncthreads();
+        // Gb: T1[al, ph] = sum_{j, ch} x[j, ch, al] Gb_i[j, ch, ph] ; Gb_{i+1}[i', al, be] = sum_ph b2[i', ph, be] T1[al, ph]
+        WG_FOR((long long)s.rr * s.br) {
+            const int al = (int)(e_ % s.rr), ph = (int)(e_ / s.rr);
+            double a = 0.0;
+            for (int ch = 0; ch < s.rl; ++ch)
+                for (int j = 0; j < s.n; ++j)
+                    a = fma(x[j + s.n * (ch + (long long)s.rl * al)], Gbi[j + s.n * (ch + (long long)s.rl * ph)], a);
+            T1[e_] = a;
+        }
+        __syncthreads();
+        WG_FOR((long long)s2.n * s.rr * s2.br) {
+            long long t = e_; const int ii = t % s2.n; t /= s2.n; const int al = t % s.rr; const int be = (int)(t / s.rr);
+            double a = 0.0;
+            for (int ph = 0; ph < s.br; ++ph) a = fma(b2[ii + s2.n * (ph + (long long)s2.bl * be)], T1[al + (long long)s.rr * ph], a);
+            Gbo[e_] = a;
+        }
+        __syncthreads();
+    };
+    // V = K \ Pb for site i (als.jl:58-70); V lands in Pb as (n, rl, rr) column-major.  Returns false on a singular system.
+    auto ksolve = [&](int i) -> bool {
+        const AlsSite s = SITE(i);
+        const double *Gi = GP(i), *Gbi = GBP(i), *Hi = HP(i), *Hbi = HBP(i);
+        const int nr = s.n * s.rl, N = nr * s.rr;
+        WG_FOR((long long)N * N) {
+            const int row = (int)(e_ % N), col = (int)(e_ / N);
+            const int ab = row % nr, c = row / nr, de = col % nr, f = col / nr;
+            double a = 0.0;
+            for (int z = 0; z < s.Rr; ++z) a = fma(Gi[ab + (long long)nr * (de + (long long)nr * z)], Hi[z + s.Rr * (c + (long long)s.rr * f)], a);
+            K[e_] = a;
+        }
+        WG_FOR(N) {
+            const int ia = (int)(e_ % nr), a2 = (int)(e_ / nr);
+            double a = 0.0;
+            for (int be = 0; be < s.br; ++be) a = fma(Gbi[ia + (long long)nr * be], Hbi[a2 + (long long)s.rr * be], a);
+            Pb[e_] = a;
+        }
+        __syncthreads();
+        return wg_lu_solve(N, K, Pb, red, iflag) == 0;
+    };
+
+    // ---- initial environments (als.jl:183-193): G_1, Gb_1 from the first cores, H / Hb from the right ----
+    {
+        const AlsSite s = SITE(0);
+        WG_FOR((long long)s.n * s.n * s.Rr) GP(0)[e_] = AC(0)[e_];                 // A_1[:, :, 1, :] as (n, 1, n, 1, R_1)
+        WG_FOR((long long)s.n * s.br) GBP(0)[e_] = BC(0)[e_];
+        if (tid == 0) { HP(d - 1)[0] = 1.0; HBP(d - 1)[0] = 1.0; }
+        __syncthreads();
+    }
+    for (int i = d - 1; i >= 1; --i) update_H(i);
+    bool ok = true;
+    int nsweeps = 0;
+    while (nsweeps < P.sweep_count && ok) {
+        ++nsweeps;
+        for (int i = 0; i < d - 1 && ok; ++i) {                                     // first half sweep (als.jl:199-207)
+            ok = ksolve(i);
+            if (!ok) break;
+            const AlsSite s = SITE(i);
+            const int mm = s.n * s.rl;
+            WG_FOR((long long)mm * s.rr) Tm[e_] = Pb[e_];
+            __syncthreads();
+            wg_qr_explicit(mm, s.rr, Tm, Qb, Rb, W, lds);                           // right_core_move (als.jl:122-135)
+            double* xi = XC(i);
+            WG_FOR((long long)mm * s.rr) xi[e_] = Qb[e_];
+            // x_{i+1}[a, b, c] = sum_z R[b, z] x_{i+1}[a, z, c]
+            const AlsSite s2 = SITE(i + 1);
+            double* xn = XC(i + 1);
+            WG_FOR((long long)s2.n * s2.rl * s2.rr) {
+                long long t = e_; const int a_ = t % s2.n; t /= s2.n; const int bq = t % s2.rl; const int c = (int)(t / s2.rl);
+                double a = 0.0;
+                for (int z = 0; z < s2.rl; ++z) a = fma(Rb[bq + (long long)s.rr * z], xn[a_ + s2.n * (z + (long long)s2.rl * c)], a);
+                T1[e_] = a;
+            }
+            __syncthreads();
+            WG_FOR((long long)s2.n * s2.rl * s2.rr) xn[e_] = T1[e_];
+            __syncthreads();
+            update_G(i);
+        }
+        if (nsweeps == P.sweep_count || !ok) break;
+        ++nsweeps;
+        for (int i = d - 1; i >= 1 && ok; --i) {                                    // second half sweep (als.jl:213-219)
+            ok = ksolve(i);
+            if (!ok) break;
+            const AlsSite s = SITE(i);
+            const int mm = s.n * s.rr;
+            // M[(x + n*a2), a1] = V[x, a1, a2]                                      left_core_move (als.jl:102-120)
+            WG_FOR((long long)mm * s.rl) {
+                const int row = (int)(e_ % mm), a1 = (int)(e_ / mm);
+                const int xx = row % s.n, a2 = row / s.n;
+                Tm[e_] = Pb[xx + s.n * (a1 + (long long)s.rl * a2)];
+            }
+            __syncthreads();
+            wg_qr_explicit(mm, s.rl, Tm, Qb, Rb, W, lds);
+            double* xi = XC(i);
+            WG_FOR((long long)mm * s.rl) {
+                const int row = (int)(e_ % mm), a1 = (int)(e_ / mm);
+                const int xx = row % s.n, a2 = row / s.n;
+                xi[xx + s.n * (a1 + (long long)s.rl * a2)] = Qb[e_];
+            }
+            // x_{i-1}[a, b, c] = sum_z x_{i-1}[a, b, z] R[c, z]
+            const AlsSite s0 = SITE(i - 1);
+            double* xp = XC(i - 1);
+            WG_FOR((long long)s0.n * s0.rl * s0.rr) {
+                const long long ab = e_ % ((long long)s0.n * s0.rl);
+                const int c = (int)(e_ / ((long long)s0.n * s0.rl));
+                double a = 0.0;
+                for (int z = 0; z < s0.rr; ++z) a = fma(xp[ab + (long long)s0.n * s0.rl * z], Rb[c + (long long)s.rl * z], a);
+                T1[e_] = a;
+            }
+            __syncthreads();
+            WG_FOR((long long)s0.n * s0.rl * s0.rr) xp[e_] = T1[e_];
+            __syncthreads();
+            update_H(i);
+        }
+    }
+    if (!ok && tid == 0) P.status[b] = 3;
+#undef XC
+#undef BC
+#undef AC
+#undef GP
+#undef GBP
+#undef HP
+#undef HBP
+#undef SITE
+#undef WG_FOR
+}

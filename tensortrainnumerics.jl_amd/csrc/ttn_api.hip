@@ -5,6 +5,7 @@
 #include "ttn_dense_kernels.h"
 #include "ttn_ortho_kernels.h"
 #include "ttn_hsvd_kernels.h"
+#include "ttn_als_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -145,6 +146,8 @@ int ttn_init(int device) {
     // the compress / orthogonalize kernels use more than the default 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compress), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(COMPRESS_LDS_BYTES)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_linsolve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ttv_decomp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_swap_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -969,11 +972,99 @@ int ttn_ttv_decomp(ttn_tt_t z, const double* tensors, int64_t index, double tol)
     return TTN_OK;
 }
 
+// ---- als_linsolve ------------------------------------------------------------------------------------------------
+int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t sweep_count) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!A || !b || !x0 || !x) return fail(TTN_ERR_ARG, "null handle");
+    if (sweep_count < 1) return fail(TTN_ERR_SWEEPS, "sweep_count must be >= 1");
+    if (!same_dims(A->dims, b->dims) || !same_dims(b->dims, x0->dims) || !same_dims(x0->dims, x->dims)) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    if (b->batch != x0->batch || x->batch != x0->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
+    const int d = x0->d;
+    if (d < 2) return fail(TTN_ERR_UNSUPPORTED, "ttn_als_linsolve: needs at least two sites");
+    // the solution keeps the ranks of the start train (als.jl:177); they must survive orthogonalize (als.jl:174) and allow
+    // the thin QRs of the core moves
+    std::vector<int64_t> capped(d + 1);
+    ttn_r_and_d_to_rks(d, x0->dims.data(), d + 1, x0->bound.data(), 1024, capped.data());
+    const std::vector<int64_t> r(x0->bound);
+    for (int k = 0; k <= d; ++k) if (capped[k] != r[k]) return fail(TTN_ERR_UNSUPPORTED, "ttn_als_linsolve: the start ranks exceed what orthogonalize keeps");
+    for (int i = 0; i < d; ++i)
+        if (x0->dims[i] * r[i] < r[i + 1] || x0->dims[i] * r[i + 1] < r[i]) return fail(TTN_ERR_UNSUPPORTED, "ttn_als_linsolve: a core is too flat for the QR core moves");
+    int rc = ttn_orthogonalize(x0, 1, x);
+    if (rc) return rc;
+    const std::vector<int64_t>& R = A->rks;
+    const std::vector<int64_t>& rb = b->bound;
+    std::vector<long long> off(4 * d);
+    long long cur = 0, Nmax = 1, mmax = 1, rmax = 1, t1 = 1, t2 = 1;
+    for (int i = 0; i < d; ++i) {
+        const long long n = x0->dims[i], rl = r[i], rr = r[i + 1], Rl = R[i], Rr = R[i + 1], bl = rb[i], br = rb[i + 1];
+        off[i] = cur; cur += n * rl * n * rl * Rr;
+        off[d + i] = cur; cur += n * rl * br;
+        off[2 * d + i] = cur; cur += Rr * rr * rr;
+        off[3 * d + i] = cur; cur += rr * br;
+        Nmax = std::max(Nmax, n * rl * rr);
+        mmax = std::max(mmax, std::max(n * rl, n * rr));
+        rmax = std::max(rmax, std::max(rl, rr));
+        t1 = std::max(t1, std::max(std::max(Rr * rr * n * rl, n * rl * rr * std::max(Rl, Rr)), std::max(rr * n * bl, std::max(rr * br, rl * br))));
+        t2 = std::max(t2, std::max(n * rr * Rl * rl, rr * rr * Rr));
+    }
+    if (Nmax > 2048) return fail(TTN_ERR_UNSUPPORTED, "ttn_als_linsolve: local systems above 2048 unknowns are not supported by the one-workgroup LU");
+    AlsArgs P;
+    memset(&P, 0, sizeof(P));
+    P.offK = cur; cur += Nmax * Nmax;
+    P.offPb = cur; cur += Nmax;
+    P.offT1 = cur; cur += t1;
+    P.offT2 = cur; cur += t2;
+    P.offTm = cur; cur += mmax * rmax;
+    P.offQb = cur; cur += mmax * rmax;
+    P.offRb = cur; cur += rmax * rmax;
+    P.offVb = cur; cur += QR_NB * mmax;
+    P.offWb = cur; cur += QR_NB * mmax;
+    P.offTst = cur; cur += ((rmax + QR_NB - 1) / QR_NB) * QR_NB * QR_NB + 64;
+    const long long per_train = cur;
+    const int batch = x->batch;
+    static std::vector<long long> h_off;               // outlives the async upload
+    HIPCHK(hipStreamSynchronize(g_stream));
+    rc = ensure_scratch(sizeof(double) * (size_t)per_train * batch + sizeof(long long) * (size_t)(5 * d + 1) + 64);
+    if (rc) return rc;
+    rc = ensure_batch_bufs(batch);
+    if (rc) return rc;
+    double* base = (double*)g_scratch;
+    long long* d_tab = (long long*)(base + (size_t)per_train * batch);
+    h_off = off;
+    for (int k = 0; k <= d; ++k) h_off.push_back(r[k]);
+    HIPCHK(hipMemcpyAsync(d_tab, h_off.data(), sizeof(long long) * h_off.size(), hipMemcpyHostToDevice, g_stream));
+    P.A = A->dev(); P.b = b->dev(); P.x = x->dev();
+    P.sweep_count = (int)sweep_count;
+    P.scratch = base; P.scratch_stride = per_train;
+    P.off = d_tab;
+    P.rfix = d_tab + 4 * d;
+    P.mmax = (int)mmax; P.rmax = (int)rmax;
+    P.status = g_status;
+    hipLaunchKernelGGL(k_als_linsolve, dim3(batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, P);
+    HIPCHK(hipGetLastError());
+    // orthogonality flags as the core moves leave them (als.jl:128-134, :112-118)
+    for (int bb = 0; bb < batch; ++bb) {
+        int64_t* ot = &x->ot[(size_t)bb * d];
+        int64_t done = 0;
+        while (done < sweep_count) {
+            ++done;
+            for (int i = 0; i + 1 < d; ++i) { ot[i] = -1; ot[i + 1] = 0; }
+            if (done == sweep_count) break;
+            ++done;
+            for (int i = d - 1; i >= 1; --i) { ot[i] = 1; ot[i - 1] = 0; }
+        }
+    }
+    return TTN_OK;
+}
+
 // status of the last dense kernel (synchronises): returns TTN_ERR_NO_CONVERGENCE if any train failed
 static int check_status(int batch) {
     std::vector<int> st(batch);
     HIPCHK(hipMemcpyAsync(st.data(), g_status, sizeof(int) * batch, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
+    for (int b = 0; b < batch; ++b) if (st[b] == 3) return fail(TTN_ERR_SINGULAR, "als_linsolve: a local system K is singular");
+    for (int b = 0; b < batch; ++b) if (st[b] == 4) return fail(TTN_ERR_DIMS, "als_linsolve: a train's ranks differ from the ranks of the start handle");
     for (int b = 0; b < batch; ++b) if (st[b] == 2) return fail(TTN_ERR_CAPACITY, "a rank grew beyond the rank capacity of its handle / working slot (site-swap chain or ttv_decomp)");
     for (int b = 0; b < batch; ++b) if (st[b]) return fail(TTN_ERR_NO_CONVERGENCE, "Jacobi SVD hit its sweep limit");
     return TTN_OK;

@@ -18,6 +18,7 @@ from __future__ import annotations
 import math
 from typing import List, Sequence
 
+from . import _lib
 from . import device as D
 from .device import DeviceTT, DeviceTTO
 
@@ -394,3 +395,23 @@ def crank_nicholson_method(A: TToperator, u0: DeviceTT, guess: DeviceTT, steps, 
                            max_bond: int = 0, **kw) -> DeviceTT:
     """src/solvers/euler.jl:142-190 (tt_solver = "krylov"; the return_error branch is not built)."""
     return _implicit_stepper(A, u0, guess, steps, normalize, tt_solver, max_bond, True, kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# als_linsolve (src/solvers/als.jl:161-222; SURVEY §8 f1) — csrc/ttn_als_kernels.h
+# ---------------------------------------------------------------------------------------------------------------------
+def als_linsolve_(A: DeviceTTO, b: DeviceTT, x0: DeviceTT, x: DeviceTT, sweep_count: int = 2) -> DeviceTT:
+    """x_b = als_linsolve(A, b_b, x0_b; sweep_count) for every train of the batch; x keeps x0's ranks."""
+    assert sweep_count >= 1, "sweep_count must be >= 1"
+    _lib.check(_lib.lib().ttn_als_linsolve(A.h, b.h, x0.h, x.h, int(sweep_count)))
+    return x
+
+
+def als_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, sweep_count: int = 2) -> TTvector:
+    """Host-level form for one right-hand side (upload, solve on the device, download)."""
+    dA = DeviceTTO(A)
+    db, dx0 = DeviceTT.from_host(b), DeviceTT.from_host(tt_start)
+    dx = DeviceTT(tt_start.ttv_dims, tt_start.ttv_rks)
+    als_linsolve_(dA, db, dx0, dx, sweep_count)
+    D.compress_status(dx)
+    return dx.download(0)

@@ -361,3 +361,32 @@ def test_ttv_decomp_reference_cases():
         tt = O.ttv_decomp(dense, index=index, tol=1e-10 * np.max(np.abs(dense)))
         assert tt.ttv_rks == x.ttv_rks
         assert np.max(np.abs(O.ttv_to_tensor(tt) - dense)) < 1e-12 * np.max(np.abs(dense))
+
+
+# ---- als_linsolve ----------------------------------------------------------------------------------------------
+def test_als_linsolve_reference_assertions():
+    """test/test_als.jl:30-77: structure, residual < 0.5 for Δ + 10 I after 4 half sweeps, identity gives x ~ b (< 0.05),
+    a single forward half sweep; plus: with full ranks two half sweeps solve the system exactly."""
+    rng = np.random.default_rng(9999)
+
+    def spd(d, shift):
+        return O.tto_add(O.Delta(d), O.tto_scale(shift, O.id_tto(d)))
+
+    def resid(A, x, b):
+        return O.norm(O.sub(O.apply(A, x), b)) / max(O.norm(b), np.finfo(float).eps)
+
+    dims, rks = (2, 2, 2), [1, 2, 2, 1]
+    x = O.als_linsolve(O.rand_tto(dims, 3, rng), O.rand_tt(dims, rks, rng), O.rand_tt(dims, rks, rng))
+    assert x.N == 3 and x.ttv_dims == dims and x.ttv_rks == rks
+    d = 4
+    A, b, x0 = spd(d, 10.0), O.rand_tt((2,) * d, [1, 2, 2, 2, 1], rng), O.rand_tt((2,) * d, [1, 2, 2, 2, 1], rng)
+    assert resid(A, O.als_linsolve(A, b, x0, sweep_count=4), b) < 0.5
+    A, b, x0 = O.id_tto(d), O.rand_tt((2,) * d, [1] * 5, rng), O.rand_tt((2,) * d, [1] * 5, rng)
+    assert resid(A, O.als_linsolve(A, b, x0, sweep_count=4), b) < 0.05
+    d = 3
+    A, b, x0 = spd(d, 5.0), O.rand_tt((2,) * d, [1, 2, 2, 1], rng), O.rand_tt((2,) * d, [1, 2, 2, 1], rng)
+    assert O.als_linsolve(A, b, x0, sweep_count=1).ttv_dims == b.ttv_dims
+    d = 5
+    A, b, x0 = spd(d, 3.0), O.rand_tt((2,) * d, 3, rng), O.rand_tt((2,) * d, [1, 2, 4, 4, 2, 1], rng)
+    dense = np.linalg.solve(O.qtto_to_matrix(A), O.qtt_to_vector(b))
+    assert np.max(np.abs(O.qtt_to_vector(O.als_linsolve(A, b, x0, sweep_count=2)) - dense)) <= 1e-11 * np.max(np.abs(dense))
