@@ -5,7 +5,7 @@
 //   local system   K[(a,b,c),(d,e,f)] = sum_z G_i[a,b,d,e,z] H_i[z,c,f] ;  Pb = Gb_i Hb_i' ;  V = K \ Pb               (als.jl:58-70)
 //   core moves     thin QR of V, R pushed into the neighbour                                                              (als.jl:102-135)
 // The reference assembles K densely and calls LAPACK's LU (`K \ b`; its it_solver keyword is ignored, :161,203): the device
-// does the same — dense K in global memory, right-looking LU with partial pivoting by the whole workgroup — so results agree
+// does the same — dense K in global memory, blocked right-looking LU with partial pivoting by the whole workgroup (trailing updates on the MFMA) — so results agree
 // to rounding * cond(K).  The contractions are staged exactly as the reference's @tensoropt orders suggest (three small stages
 // each); at ALS sizes they are latency-, not flop-bound, and run on the VALU.  Local sizes n*r*r up to 2048 are supported.
 #pragma once
@@ -18,49 +18,100 @@ struct AlsArgs {
     double* scratch;
     long long scratch_stride;
     const long long* off;        // device [4][d]: offsets of G_i, Gb_i, H_i, Hb_i in the per-train scratch
-    long long offK, offPb, offT1, offT2, offTm, offQb, offRb, offVb, offWb, offTst;
+    long long offK, offPb, offPiv, offT1, offT2, offTm, offQb, offRb, offVb, offWb, offTst;
     int mmax, rmax;
     int* status;                 // [batch]: 0 ok, 3 singular local system, 4 ranks differ from the handle's bound
     const long long* rfix;       // device [d+1]: the fixed ranks of x
 };
 
-// out-of-line helper: dense solve K v = rhs (in place, v overwrites rhs); K is N x N column-major (destroyed).
-// Right-looking LU with partial pivoting (first maximal |entry| like LAPACK's idamax), forward elimination applied to
-// the right-hand side on the fly, then back substitution.  Returns 0, or 1 if a pivot is exactly zero.
-__device__ __noinline__ int wg_lu_solve(int N, double* K, double* rhs, double* red, int* iflag) {
-    N = uni32(N); K = unip(K); rhs = unip(rhs); red = unip(red); iflag = unip(iflag);
+// Dense solve K v = rhs (in place, v overwrites rhs); K is N x N column-major (destroyed).  Blocked right-looking LU with
+// partial pivoting (first maximal |entry| of the column, like LAPACK's idamax): panels of LU_NB columns are factored column
+// by column inside the panel, the row interchanges are then applied to the rest of the matrix and to the right-hand side,
+// U12 = L11^-1 A12 by forward substitution (one column per thread), and the trailing block gets A22 -= L21 U12 as ONE MFMA
+// GEMM (wg_gemm, alpha = -1, beta = 1) — that GEMM carries the 2/3 N^3 flops.  The right-hand side is eliminated on the fly;
+// back substitution at the end.  Returns 0, or 1 if a pivot is exactly zero (LAPACK: SingularException).
+#define LU_NB 32
+__device__ __noinline__ int wg_lu_solve(int N, double* K, double* rhs, int* piv, double* red, int* iflag, double* lds) {
+    N = uni32(N); K = unip(K); rhs = unip(rhs); piv = unip(piv); red = unip(red); iflag = unip(iflag); lds = unip(lds);
     const int tid = threadIdx.x;
-    for (int k = 0; k < N; ++k) {
-        double* colk = K + (long long)k * N;
-        double vm = 0.0;
-        for (int i = k + tid; i < N; i += TTN_WG) vm = fmax(vm, fabs(colk[i]));
-        if (tid == 0) iflag[0] = N;
-        vm = unif64(wg_max(vm, red));                       // barriers inside: iflag[0] is visible after it
-        if (!(vm > 0.0)) return 1;
-        for (int i = k + tid; i < N; i += TTN_WG) if (fabs(colk[i]) == vm) atomicMin(&iflag[0], i);
-        __syncthreads();
-        const int pv = uni32(iflag[0]);
-        __syncthreads();
-        if (pv != k) {
-            for (int j = tid; j < N; j += TTN_WG) { const double t = K[(long long)j * N + k]; K[(long long)j * N + k] = K[(long long)j * N + pv]; K[(long long)j * N + pv] = t; }
-            if (tid == 0) { const double t = rhs[k]; rhs[k] = rhs[pv]; rhs[pv] = t; }
+    for (int k0 = 0; k0 < N; k0 += LU_NB) {
+        const int w = min(LU_NB, N - k0);
+        // ---- (a) the panel, column by column ----
+        for (int j = k0; j < k0 + w; ++j) {
+            double* colj = K + (long long)j * N;
+            double vm = 0.0;
+            for (int i = j + tid; i < N; i += TTN_WG) vm = fmax(vm, fabs(colj[i]));
+            if (tid == 0) iflag[0] = N;
+            vm = unif64(wg_max(vm, red));                   // barriers inside: iflag[0] is visible after it
+            if (!(vm > 0.0)) return 1;
+            for (int i = j + tid; i < N; i += TTN_WG) if (fabs(colj[i]) == vm) atomicMin(&iflag[0], i);
+            __syncthreads();
+            const int pv = uni32(iflag[0]);
+            if (tid == 0) piv[j] = pv;
+            if (pv != j && tid < w) {                        // interchange inside the panel now, outside it in (b)
+                double* c = K + (long long)(k0 + tid) * N;
+                const double t = c[j]; c[j] = c[pv]; c[pv] = t;
+            }
+            __syncthreads();
+            const double pivot = colj[j];
+            for (int i = j + 1 + tid; i < N; i += TTN_WG) colj[i] = colj[i] / pivot;
+            __syncthreads();
+            const int m = N - j - 1, nc = k0 + w - j - 1;    // rank-1 update of the rest of the panel
+            for (long long e = tid; e < (long long)m * nc; e += TTN_WG) {
+                const int i = j + 1 + (int)(e % m), c = j + 1 + (int)(e / m);
+                K[(long long)c * N + i] = fma(-colj[i], K[(long long)c * N + j], K[(long long)c * N + i]);
+            }
             __syncthreads();
         }
-        const double piv = colk[k];
-        for (int i = k + 1 + tid; i < N; i += TTN_WG) colk[i] = colk[i] / piv;
-        __syncthreads();
-        const int m = N - k - 1;
-        // trailing update: K[i, j] -= l_i * K[k, j]; i fastest (coalesced)
-        for (long long e = tid; e < (long long)m * m; e += TTN_WG) {
-            const int i = k + 1 + (int)(e % m), j = k + 1 + (int)(e / m);
-            K[(long long)j * N + i] = fma(-colk[i], K[(long long)j * N + k], K[(long long)j * N + i]);
+        // ---- (b) the panel's interchanges on the other columns (a thread owns a column: order kept) and on the rhs ----
+        for (int c = tid; c < N + 1; c += TTN_WG) {
+            if (c >= k0 && c < k0 + w) continue;
+            double* col = (c == N) ? rhs : K + (long long)c * N;
+            for (int j = k0; j < k0 + w; ++j) {
+                const int pv = piv[j];
+                if (pv != j) { const double t = col[j]; col[j] = col[pv]; col[pv] = t; }
+            }
         }
-        const double rk = rhs[k];
         __syncthreads();
-        for (int i = k + 1 + tid; i < N; i += TTN_WG) rhs[i] = fma(-colk[i], rk, rhs[i]);
+        // ---- (c) U12 = L11^-1 A12 and the same for the rhs: forward substitution with the unit lower triangle of the panel,
+        //      staged in LDS (zero padded to LU_NB) so that a thread keeps its column segment in registers ----
+        lds_f64* L11 = (lds_f64*)lds;
+        for (int e = tid; e < LU_NB * LU_NB; e += TTN_WG) {
+            const int ii = e % LU_NB, jj = e / LU_NB;
+            L11[e] = (ii < w && jj < w && ii > jj) ? K[(long long)(k0 + jj) * N + k0 + ii] : 0.0;
+        }
+        __syncthreads();
+        for (int c = k0 + w + tid; c < N + 1; c += TTN_WG) {
+            double* col = (c == N) ? rhs : K + (long long)c * N;
+            double u[LU_NB];
+#pragma unroll
+            for (int ii = 0; ii < LU_NB; ++ii) u[ii] = (ii < w) ? col[k0 + ii] : 0.0;
+#pragma unroll
+            for (int jj = 0; jj < LU_NB - 1; ++jj) {
+#pragma unroll
+                for (int ii = jj + 1; ii < LU_NB; ++ii) u[ii] = fma(-L11[jj * LU_NB + ii], u[jj], u[ii]);
+            }
+#pragma unroll
+            for (int ii = 0; ii < LU_NB; ++ii) if (ii < w) col[k0 + ii] = u[ii];
+        }
+        __syncthreads();
+        const int m = N - k0 - w;
+        if (m > 0) {
+            // rhs[i] -= sum_jj L21[i, jj] rhs[k0 + jj]
+            for (int i = k0 + w + tid; i < N; i += TTN_WG) {
+                double a = rhs[i];
+                for (int jj = 0; jj < w; ++jj) a = fma(-K[(long long)(k0 + jj) * N + i], rhs[k0 + jj], a);
+                rhs[i] = a;
+            }
+            // ---- (d) A22 -= L21 U12 ----
+            const View L21 = mkview(K + (long long)k0 * N + (k0 + w), plain(1), plain(N));                 // m x w
+            const View U12 = mkview(K + (long long)(k0 + w) * N + k0, plain(1), plain(N));                 // w x m
+            const View A22 = mkview(K + (long long)(k0 + w) * N + (k0 + w), plain(1), plain(N));           // m x m
+            wg_gemm(m, m, w, L21, U12, A22, -1.0, 1.0, lds);
+        }
         __syncthreads();
     }
-    for (int k = N - 1; k >= 0; --k) {
+    for (int k = N - 1; k >= 0; --k) {                       // back substitution with U
         const double* colk = K + (long long)k * N;
         const double xk = rhs[k] / colk[k];
         __syncthreads();
@@ -233,7 +284,7 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
             Pb[e_] = a;
         }
         __syncthreads();
-        return wg_lu_solve(N, K, Pb, red, iflag) == 0;
+        return wg_lu_solve(N, K, Pb, reinterpret_cast<int*>(scr + P.offPiv), red, iflag, lds) == 0;
     };
 
     // ---- initial environments (als.jl:183-193): G_1, Gb_1 from the first cores, H / Hb from the right ----

@@ -1013,6 +1013,7 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
     memset(&P, 0, sizeof(P));
     P.offK = cur; cur += Nmax * Nmax;
     P.offPb = cur; cur += Nmax;
+    P.offPiv = cur; cur += Nmax / 2 + 8;               // Nmax ints
     P.offT1 = cur; cur += t1;
     P.offT2 = cur; cur += t2;
     P.offTm = cur; cur += mmax * rmax;
