@@ -140,6 +140,12 @@ int ttn_ttv_decomp(ttn_tt_t z, const double* tensors, int64_t index, double tol)
  * the same ranks; n r_{i-1} r_i <= 2048.  ttn_compress_status(x) reports a singular local system (TTN_ERR_SINGULAR). */
 int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t sweep_count);
 
+/* mals_linsolve(A, b, tt_start; tol, rmax) (src/solvers/mals.jl:240-312): one forward and one backward half sweep of
+ * two-site solves, ranks adapted by the truncated SVD of every local solution (sv_trunc, clamped to rmax).  x receives
+ * orthogonalize(x0) first; x's CAPACITY bounds the ranks (a larger rank: TTN_ERR_CAPACITY through ttn_compress_status) and
+ * must keep every two-site system n_i cap_i n_{i+1} cap_{i+2} <= 2048. */
+int ttn_mals_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t rmax);
+
 /* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);
 

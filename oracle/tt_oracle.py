@@ -38,7 +38,7 @@ __all__ = [
     "tt_compress_", "copy_tt", "rk4_method", "euler_method",
     "ttm_swap_", "ttm_contract_", "hadamard_ttm", "swap_adjacent_sites", "bubble_sort_swaps", "reorder_perm",
     "swap_sites_", "reorder", "swap_adjacent_sites_op", "reorder_op", "ttv_decomp",
-    "als_linsolve", "tto_add", "tto_scale",
+    "als_linsolve", "tto_add", "tto_scale", "mals_linsolve", "sv_trunc",
 ]
 
 
@@ -837,6 +837,88 @@ def als_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, sweep_count: in
             x.ttv_ot[i - 1] = 0
             H[i - 1] = _als_update_H(x.ttv_vec[i], A.tto_vec[i], H[i])
             Hb[i - 1] = _als_update_Hb(x.ttv_vec[i], b.ttv_vec[i], Hb[i])
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# mals_linsolve — src/solvers/mals.jl:10-168 (environments, two-site solve, SVD core moves), :240-312
+# --------------------------------------------------------------------------------------
+def sv_trunc(s: np.ndarray, tol: float) -> np.ndarray:
+    """sv_trunc (src/solvers/mals.jl:42-56): drops the tail while its weight stays below tol * ||s||^2 — and keeps the value
+    that crossed the line."""
+    if tol == 0.0:
+        return s
+    d = len(s)
+    i = 0
+    weight = 0.0
+    norm2 = float(np.sum(np.abs(s) ** 2))
+    while i < d and weight < tol * norm2:
+        weight += float(s[d - i - 1]) ** 2
+        i += 1
+    return s[: d - i + 1]
+
+
+def mals_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1.0e-12, rmax: int | None = None) -> TTvector:
+    """mals_linsolve(A, b, tt_start; tol, rmax) (src/solvers/mals.jl:240-312): one forward and one backward half sweep of
+    two-site solves with dense local systems; ranks adapt through the truncated SVD of every local solution."""
+    d = b.N
+    dims = tuple(tt_start.ttv_dims)
+    if rmax is None:
+        rmax = int(round(math.sqrt(_prod(dims))))
+    x = orthogonalize(tt_start)
+    G = [None] * d
+    Gb = [None] * d
+    G[0] = np.reshape(A.tto_vec[0][:, :, 0, :], (dims[0], 1, dims[0], 1, -1))
+    Gb[0] = np.reshape(b.ttv_vec[0], (dims[0], 1, -1))
+    # H[i] (0-based i = 0..d-2) couples sites i, i+1: (R_{i+1}, n_{i+1}, r_{i+2}, n_{i+1}, r_{i+2})    (:15-40)
+    H = [None] * (d - 1)
+    Hb = [None] * (d - 1)
+    H[d - 2] = np.reshape(np.transpose(A.tto_vec[d - 1], (2, 0, 1, 3)), (-1, dims[d - 1], 1, dims[d - 1], 1))
+    Hb[d - 2] = np.reshape(np.transpose(b.ttv_vec[d - 1], (1, 0, 2)), (b.ttv_rks[d - 1], dims[d - 1], 1))
+    for i in range(d - 2, 0, -1):
+        # Him[a, i, al, l, be] = conj(x)[j, al, x] * (Hi[z, j, x, k, y] * x[k, be, y]) * A[i, l, a, z]      (:10-13), x = core i+1
+        H[i - 1] = np.einsum("jax,zjxky,kby,ilwz->wialb", x.ttv_vec[i + 1], H[i], x.ttv_vec[i + 1], A.tto_vec[i], optimize=True)
+        # Hbim[be, i, ch] = conj(x)[j, ch, a] * Hbi[ga, j, a] * b[i, be, ga]                                  (:60-66)
+        Hb[i - 1] = np.einsum("jca,gja,ibg->bic", x.ttv_vec[i + 1], Hb[i], b.ttv_vec[i], optimize=True)
+
+    def ksolve(i):
+        Gi, Hi, Gbi, Hbi = G[i], H[i], Gb[i], Hb[i]
+        kd = (Gi.shape[0], Gi.shape[1], Hi.shape[1], Hi.shape[2])
+        N = kd[0] * kd[1] * kd[2] * kd[3]
+        K = np.reshape(np.einsum("abefz,zcdgh->abcdefgh", Gi, Hi), (N, N), order="F")       # :148-157
+        Pb = np.einsum("abz,zcd->abcd", Gbi, Hbi)                                            # :165
+        # `Hermitian(K) \ b`: LAPACK's symmetric-indefinite solve on the upper triangle of K
+        Ku = np.triu(K) + np.triu(K, 1).T
+        V = sla.solve(Ku, np.reshape(Pb, N, order="F"), assume_a="sym")
+        return np.reshape(V, kd, order="F")
+
+    def split(V):
+        M = np.reshape(V, (V.shape[0] * V.shape[1], -1), order="F")
+        u, sv, vt = sla.svd(M, full_matrices=False, lapack_driver="gesdd")
+        r = min(len(sv_trunc(sv, tol)), rmax)
+        return u, sv, vt, r
+
+    for i in range(d - 1):                                           # first half sweep (:268-283)
+        V = ksolve(i)
+        u, sv, vt, r = split(V)
+        x.ttv_rks[i + 1] = r
+        x.ttv_vec[i] = np.reshape(u[:, :r], (V.shape[0], V.shape[1], r), order="F")          # right_core_move_mals (:121-146)
+        x.ttv_ot[i] = -1
+        x.ttv_vec[i + 1] = np.transpose(np.reshape(sv[:r, None] * vt[:r, :], (r, V.shape[2], V.shape[3]), order="F"), (1, 0, 2)).copy()
+        x.ttv_ot[i + 1] = 0
+        G[i + 1] = _als_update_G(x.ttv_vec[i], A.tto_vec[i + 1], G[i])
+        Gb[i + 1] = _als_update_Gb(x.ttv_vec[i], b.ttv_vec[i + 1], Gb[i])
+    for i in range(d - 2, -1, -1):                                   # second half sweep (:286-305)
+        V = ksolve(i)
+        u, sv, vt, r = split(V)
+        x.ttv_rks[i + 1] = r
+        x.ttv_vec[i + 1] = np.transpose(np.reshape(vt[:r, :], (r, V.shape[2], V.shape[3]), order="F"), (1, 0, 2)).copy()   # left_core_move_mals (:94-119)
+        x.ttv_vec[i] = np.reshape(u[:, :r] * sv[None, :r], (V.shape[0], V.shape[1], r), order="F")
+        x.ttv_ot[i + 1] = 1
+        x.ttv_ot[i] = 0
+        if i > 0:
+            H[i - 1] = np.einsum("jax,zjxky,kby,ilwz->wialb", x.ttv_vec[i + 1], H[i], x.ttv_vec[i + 1], A.tto_vec[i], optimize=True)
+            Hb[i - 1] = np.einsum("jca,gja,ibg->bic", x.ttv_vec[i + 1], Hb[i], b.ttv_vec[i], optimize=True)
     return x
 
 

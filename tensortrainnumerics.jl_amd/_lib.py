@@ -69,6 +69,7 @@ SIGNATURES = {
     "ttn_swap_sites": (C.c_int, [handle, i64, p_i64, C.c_double]),
     "ttn_ttv_decomp": (C.c_int, [handle, C.c_void_p, i64, C.c_double]),
     "ttn_als_linsolve": (C.c_int, [handle, handle, handle, handle, i64]),
+    "ttn_mals_linsolve": (C.c_int, [handle, handle, handle, handle, C.c_double, i64]),
     "ttn_add": (C.c_int, [handle, handle, handle]),
     "ttn_scale": (C.c_int, [C.c_double, handle, handle]),
     "ttn_scale_batch": (C.c_int, [p_f64, handle, handle]),

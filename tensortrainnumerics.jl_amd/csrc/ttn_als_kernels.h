@@ -122,7 +122,78 @@ __device__ __noinline__ int wg_lu_solve(int N, double* K, double* rhs, int* piv,
     return 0;
 }
 
+// Shared by als_linsolve and mals_linsolve: G_{i+1}, Gb_{i+1} from site i (als.jl:47-55).  `xr` = the ranks of x to use.
+struct AlsEnv {
+    TTODev A; TTDev b, x;
+    int tb;                      // train
+    double* scr; const long long* off; const long long *xr, *br;
+    double *T1, *T2;
+    int d;
+};
+#define XC(i) (E.x.data + (long long)E.tb * E.x.stride + E.x.off[i])
+#define BC(i) (E.b.data + (long long)E.tb * E.b.stride + E.b.off[i])
+#define AC(i) (E.A.data + E.A.off[i])
+#define GP(i) (E.scr + E.off[i])
+#define GBP(i) (E.scr + E.off[E.d + (i)])
+#define HP(i) (E.scr + E.off[2 * E.d + (i)])
+#define HBP(i) (E.scr + E.off[3 * E.d + (i)])
+#define SITE(i) AlsSite{uni32(E.x.dims[i]), uni32((int)E.xr[i]), uni32((int)E.xr[(i) + 1]), uni32((int)E.A.rks[i]), uni32((int)E.A.rks[(i) + 1]), \
+                        uni32((int)E.br[i]), uni32((int)E.br[(i) + 1])}
+#define WG_FOR(total) for (long long e_ = threadIdx.x; e_ < (long long)(total); e_ += TTN_WG)
 struct AlsSite { int n, rl, rr, Rl, Rr, bl, br; };
+__device__ __noinline__ void als_update_G(const AlsEnv& E, int i) {
+    double* T1 = E.T1; double* T2 = E.T2;
+    const AlsSite s = SITE(i);
+    const AlsSite s2 = SITE(i + 1);
+    const double *x = XC(i), *A2 = AC(i + 1), *Gi = GP(i), *Gbi = GBP(i), *b2 = BC(i + 1);
+    double *Go = GP(i + 1), *Gbo = GBP(i + 1);
+    // T1[l, ph, be, L] = sum_{m, ch} Gi[l, ph, m, ch, L] x[m, ch, be]
+    WG_FOR((long long)s.n * s.rl * s.rr * s.Rr) {
+        long long t = e_; const int l = t % s.n; t /= s.n; const int ph = t % s.rl; t /= s.rl; const int be = t % s.rr; const int L = (int)(t / s.rr);
+        double a = 0.0;
+        for (int ch = 0; ch < s.rl; ++ch)
+            for (int m = 0; m < s.n; ++m)
+                a = fma(Gi[l + s.n * (ph + (long long)s.rl * (m + (long long)s.n * (ch + (long long)s.rl * L)))], x[m + s.n * (ch + (long long)s.rl * be)], a);
+        T1[e_] = a;
+    }
+    __syncthreads();
+    // T2[al, be, L] = sum_{l, ph} x[l, ph, al] T1[l, ph, be, L]
+    WG_FOR((long long)s.rr * s.rr * s.Rr) {
+        long long t = e_; const int al = t % s.rr; t /= s.rr; const int be = t % s.rr; const int L = (int)(t / s.rr);
+        double a = 0.0;
+        for (int ph = 0; ph < s.rl; ++ph)
+            for (int l = 0; l < s.n; ++l)
+                a = fma(x[l + s.n * (ph + (long long)s.rl * al)], T1[l + s.n * (ph + (long long)s.rl * (be + (long long)s.rr * L))], a);
+        T2[e_] = a;
+    }
+    __syncthreads();
+    // G_{i+1}[j, al, k, be, J] = sum_L T2[al, be, L] A2[j, k, L, J]
+    WG_FOR((long long)s2.n * s.rr * s2.n * s.rr * s2.Rr) {
+        long long t = e_; const int j = t % s2.n; t /= s2.n; const int al = t % s.rr; t /= s.rr; const int k = t % s2.n; t /= s2.n; const int be = t % s.rr; const int J = (int)(t / s.rr);
+        double a = 0.0;
+        for (int L = 0; L < s.Rr; ++L)
+            a = fma(T2[al + s.rr * (be + (long long)s.rr * L)], A2[j + s2.n * (k + s2.n * (L + (long long)s2.Rl * J))], a);
+        Go[e_] = a;
+    }
+    __syncthreads();
+    // Gb: T1[al, ph] = sum_{j, ch} x[j, ch, al] Gb_i[j, ch, ph] ; Gb_{i+1}[i', al, be] = sum_ph b2[i', ph, be] T1[al, ph]
+    WG_FOR((long long)s.rr * s.br) {
+        const int al = (int)(e_ % s.rr), ph = (int)(e_ / s.rr);
+        double a = 0.0;
+        for (int ch = 0; ch < s.rl; ++ch)
+            for (int j = 0; j < s.n; ++j)
+                a = fma(x[j + s.n * (ch + (long long)s.rl * al)], Gbi[j + s.n * (ch + (long long)s.rl * ph)], a);
+        T1[e_] = a;
+    }
+    __syncthreads();
+    WG_FOR((long long)s2.n * s.rr * s2.br) {
+        long long t = e_; const int ii = t % s2.n; t /= s2.n; const int al = t % s.rr; const int be = (int)(t / s.rr);
+        double a = 0.0;
+        for (int ph = 0; ph < s.br; ++ph) a = fma(b2[ii + s2.n * (ph + (long long)s2.bl * be)], T1[al + (long long)s.rr * ph], a);
+        Gbo[e_] = a;
+    }
+    __syncthreads();
+}
 
 __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
     extern __shared__ double lds[];
@@ -150,17 +221,8 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
         if (bad) { if (tid == 0) P.status[b] = 4; return; }
     }
     const long long* br_ = P.b.rks + (long long)b * (d + 1);
-#define XC(i) (P.x.data + (long long)b * P.x.stride + P.x.off[i])
-#define BC(i) (P.b.data + (long long)b * P.b.stride + P.b.off[i])
-#define AC(i) (P.A.data + P.A.off[i])
-#define GP(i) (scr + P.off[i])
-#define GBP(i) (scr + P.off[d + (i)])
-#define HP(i) (scr + P.off[2 * d + (i)])
-#define HBP(i) (scr + P.off[3 * d + (i)])
-#define SITE(i) AlsSite{uni32(P.x.dims[i]), uni32((int)P.rfix[i]), uni32((int)P.rfix[(i) + 1]), uni32((int)P.A.rks[i]), uni32((int)P.A.rks[(i) + 1]), \
-                        uni32((int)br_[i]), uni32((int)br_[(i) + 1])}
-#define WG_FOR(total) for (long long e_ = tid; e_ < (long long)(total); e_ += TTN_WG)
-
+    AlsEnv E;
+    E.A = P.A; E.b = P.b; E.x = P.x; E.tb = b; E.scr = scr; E.off = P.off; E.xr = P.rfix; E.br = br_; E.T1 = T1; E.T2 = T2; E.d = d;
     // H_{i-1} from site i (als.jl:23-26) and Hb_{i-1} (als.jl:42-45)
     auto update_H = [&](int i) {
         const AlsSite s = SITE(i);
@@ -209,59 +271,6 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
                 for (int ii = 0; ii < s.n; ++ii)
                     a = fma(x[ii + s.n * (al + (long long)s.rl * ph)], T1[ph + s.rr * (ii + (long long)s.n * be)], a);
             Hbo[e_] = a;
-        }
-        __syncthreads();
-    };
-    // G_{i+1}, Gb_{i+1} from site i (als.jl:47-55)
-    auto update_G = [&](int i) {
-        const AlsSite s = SITE(i);
-        const AlsSite s2 = SITE(i + 1);
-        const double *x = XC(i), *A2 = AC(i + 1), *Gi = GP(i), *Gbi = GBP(i), *b2 = BC(i + 1);
-        double *Go = GP(i + 1), *Gbo = GBP(i + 1);
-        // T1[l, ph, be, L] = sum_{m, ch} Gi[l, ph, m, ch, L] x[m, ch, be]
-        WG_FOR((long long)s.n * s.rl * s.rr * s.Rr) {
-            long long t = e_; const int l = t % s.n; t /= s.n; const int ph = t % s.rl; t /= s.rl; const int be = t % s.rr; const int L = (int)(t / s.rr);
-            double a = 0.0;
-            for (int ch = 0; ch < s.rl; ++ch)
-                for (int m = 0; m < s.n; ++m)
-                    a = fma(Gi[l + s.n * (ph + (long long)s.rl * (m + (long long)s.n * (ch + (long long)s.rl * L)))], x[m + s.n * (ch + (long long)s.rl * be)], a);
-            T1[e_] = a;
-        }
-        __syncthreads();
-        // T2[al, be, L] = sum_{l, ph} x[l, ph, al] T1[l, ph, be, L]
-        WG_FOR((long long)s.rr * s.rr * s.Rr) {
-            long long t = e_; const int al = t % s.rr; t /= s.rr; const int be = t % s.rr; const int L = (int)(t / s.rr);
-            double a = 0.0;
-            for (int ph = 0; ph < s.rl; ++ph)
-                for (int l = 0; l < s.n; ++l)
-                    a = fma(x[l + s.n * (ph + (long long)s.rl * al)], T1[l + s.n * (ph + (long long)s.rl * (be + (long long)s.rr * L))], a);
-            T2[e_] = a;
-        }
-        __syncthreads();
-        // G_{i+1}[j, al, k, be, J] = sum_L T2[al, be, L] A2[j, k, L, J]
-        WG_FOR((long long)s2.n * s.rr * s2.n * s.rr * s2.Rr) {
-            long long t = e_; const int j = t % s2.n; t /= s2.n; const int al = t % s.rr; t /= s.rr; const int k = t % s2.n; t /= s2.n; const int be = t % s.rr; const int J = (int)(t / s.rr);
-            double a = 0.0;
-            for (int L = 0; L < s.Rr; ++L)
-                a = fma(T2[al + s.rr * (be + (long long)s.rr * L)], A2[j + s2.n * (k + s2.n * (L + (long long)s2.Rl * J))], a);
-            Go[e_] = a;
-        }
-        __syncthreads();
-        // Gb: T1[al, ph] = sum_{j, ch} x[j, ch, al] Gb_i[j, ch, ph] ; Gb_{i+1}[i', al, be] = sum_ph b2[i', ph, be] T1[al, ph]
-        WG_FOR((long long)s.rr * s.br) {
-            const int al = (int)(e_ % s.rr), ph = (int)(e_ / s.rr);
-            double a = 0.0;
-            for (int ch = 0; ch < s.rl; ++ch)
-                for (int j = 0; j < s.n; ++j)
-                    a = fma(x[j + s.n * (ch + (long long)s.rl * al)], Gbi[j + s.n * (ch + (long long)s.rl * ph)], a);
-            T1[e_] = a;
-        }
-        __syncthreads();
-        WG_FOR((long long)s2.n * s.rr * s2.br) {
-            long long t = e_; const int ii = t % s2.n; t /= s2.n; const int al = t % s.rr; const int be = (int)(t / s.rr);
-            double a = 0.0;
-            for (int ph = 0; ph < s.br; ++ph) a = fma(b2[ii + s2.n * (ph + (long long)s2.bl * be)], T1[al + (long long)s.rr * ph], a);
-            Gbo[e_] = a;
         }
         __syncthreads();
     };
@@ -322,7 +331,7 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
             __syncthreads();
             WG_FOR((long long)s2.n * s2.rl * s2.rr) xn[e_] = T1[e_];
             __syncthreads();
-            update_G(i);
+            als_update_G(E, i);
         }
         if (nsweeps == P.sweep_count || !ok) break;
         ++nsweeps;
@@ -362,6 +371,180 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
         }
     }
     if (!ok && tid == 0) P.status[b] = 3;
+}
+
+// -------------------------------------------------------------------------------------------------
+// mals_linsolve (src/solvers/mals.jl:240-312): one forward and one backward half sweep of TWO-site solves; the ranks adapt
+// through the truncated SVD of every local solution (sv_trunc, :42-56, clamped to rmax).  Same machinery as als_linsolve:
+// dense K[(a,b,c,d),(e,f,g,h)] = sum_z G_i[a,b,e,f,z] H_i[z,c,d,g,h] (:148-157) solved by the blocked LU (the reference's
+// Hermitian(K) \ b reads one triangle; K is symmetric to rounding), the split by the Householder-LQ + Jacobi SVD of the bond
+// step (wg_hsvd_step, layouts 2 / 1).  Ranks change per train, so the environments are stored compactly with the CURRENT
+// ranks inside slots sized by the handle's capacity.
+//   H_i  (R_{i+1}, n_{i+1}, r_{i+2}, n_{i+1}, r_{i+2})   couples sites i, i+1          (:10-40)
+//   Hb_i (rb_{i+1}, n_{i+1}, r_{i+2})                                                  (:60-92)
+// -------------------------------------------------------------------------------------------------
+struct MalsArgs {
+    AlsArgs L;                   // operator, handles, scratch offsets (off[2d..], off[3d..] = the MALS H / Hb slots)
+    CompressArgs C;              // Jacobi knobs, status, sweep statistics for wg_hsvd_step (C.scratch unused)
+    double tol;
+    int rmax;
+    long long offM2, offXg, offUs, offSig;     // SVD scratch
+    int pmax, qmax;
+};
+
+__global__ void __launch_bounds__(TTN_WG) k_mals_linsolve(MalsArgs Q) {
+    extern __shared__ double lds[];
+    const AlsArgs& P = Q.L;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int d = P.x.d;
+    double* scr = P.scratch + (long long)b * P.scratch_stride;
+    double* red = lds + GEMM_LDS_TOTAL;
+    BondCtx S;
+    S.ldsX = lds;
+    S.red = red;
+    S.Ts = S.red + 32;
+    S.Ss = S.Ts + QR_NB * QR_NB;
+    S.taus = S.Ss + QR_NB * QR_NB;
+    S.scal = S.taus + QR_NB;
+    S.iflag = reinterpret_cast<int*>(S.scal + 8);
+    S.nrm2 = S.scal + 16;
+    S.M = nullptr; S.M2 = nullptr;
+    S.Vb = scr + P.offVb; S.Wb = scr + P.offWb;
+    S.Us = scr + Q.offUs; S.Xg = scr + Q.offXg;
+    S.sig = scr + Q.offSig; S.sigs = S.sig + Q.pmax; S.perm = reinterpret_cast<int*>(S.sigs + Q.pmax);
+    S.Ga = S.Gb = S.Cc = S.T1 = S.T2 = S.T3 = nullptr;
+    double* K = scr + P.offK;
+    double* Pb = scr + P.offPb;
+    double* T1 = scr + P.offT1;
+    double* T2 = scr + P.offT2;
+    double* M2 = scr + Q.offM2;
+    int* piv = reinterpret_cast<int*>(scr + P.offPiv);
+    if (tid == 0) { P.status[b] = 0; Q.C.sweep_stats[b] = 0; }
+    long long* xr = P.x.rks + (long long)b * (d + 1);
+    const long long* br_ = P.b.rks + (long long)b * (d + 1);
+    AlsEnv E;
+    E.A = P.A; E.b = P.b; E.x = P.x; E.tb = b; E.scr = scr; E.off = P.off; E.xr = xr; E.br = br_; E.T1 = T1; E.T2 = T2; E.d = d;
+    __syncthreads();
+
+    // H_{i-1}, Hb_{i-1} from core i+1 of x, A_i, b_i and H_i, Hb_i   (mals.jl:10-13, :60-66)
+    auto update_H = [&](int i) {
+        const int n1 = uni32(P.x.dims[i]), n2 = uni32(P.x.dims[i + 1]);
+        const int r1 = uni32((int)xr[i + 1]), r2 = uni32((int)xr[i + 2]);
+        const int Ra = uni32((int)P.A.rks[i]), Rz = uni32((int)P.A.rks[i + 1]);
+        const int ba = uni32((int)br_[i]), bz = uni32((int)br_[i + 1]);
+        const double *x = XC(i + 1), *A = AC(i), *Hi = HP(i), *Hbi = HBP(i), *bb = BC(i);
+        double *Ho = HP(i - 1), *Hbo = HBP(i - 1);
+        // T1[z, j, xx, be] = sum_{k, y} Hi[z, j, xx, k, y] x[k, be, y]
+        WG_FOR((long long)Rz * n2 * r2 * r1) {
+            long long t = e_; const int z = t % Rz; t /= Rz; const int j = t % n2; t /= n2; const int xx = t % r2; const int be = (int)(t / r2);
+            double a = 0.0;
+            for (int y = 0; y < r2; ++y)
+                for (int k = 0; k < n2; ++k)
+                    a = fma(Hi[z + Rz * (j + n2 * (xx + (long long)r2 * (k + (long long)n2 * y)))], x[k + n2 * (be + (long long)r1 * y)], a);
+            T1[e_] = a;
+        }
+        __syncthreads();
+        // T2[z, al, be] = sum_{j, xx} x[j, al, xx] T1[z, j, xx, be]
+        WG_FOR((long long)Rz * r1 * r1) {
+            long long t = e_; const int z = t % Rz; t /= Rz; const int al = t % r1; const int be = (int)(t / r1);
+            double a = 0.0;
+            for (int xx = 0; xx < r2; ++xx)
+                for (int j = 0; j < n2; ++j)
+                    a = fma(x[j + n2 * (al + (long long)r1 * xx)], T1[z + Rz * (j + n2 * (xx + (long long)r2 * be))], a);
+            T2[e_] = a;
+        }
+        __syncthreads();
+        // H_{i-1}[a, ii, al, l, be] = sum_z T2[z, al, be] A[ii, l, a, z]
+        WG_FOR((long long)Ra * n1 * r1 * n1 * r1) {
+            long long t = e_; const int a_ = t % Ra; t /= Ra; const int ii = t % n1; t /= n1; const int al = t % r1; t /= r1; const int l = t % n1; const int be = (int)(t / n1);
+            double a = 0.0;
+            for (int z = 0; z < Rz; ++z) a = fma(T2[z + Rz * (al + (long long)r1 * be)], A[ii + n1 * (l + n1 * (a_ + (long long)Ra * z))], a);
+            Ho[e_] = a;
+        }
+        __syncthreads();
+        // Hb: T1[ga, ch] = sum_{j, a} x[j, ch, a] Hbi[ga, j, a] ; Hb_{i-1}[be, ii, ch] = sum_ga b[ii, be, ga] T1[ga, ch]
+        WG_FOR((long long)bz * r1) {
+            const int ga = (int)(e_ % bz), ch = (int)(e_ / bz);
+            double a = 0.0;
+            for (int aa = 0; aa < r2; ++aa)
+                for (int j = 0; j < n2; ++j)
+                    a = fma(x[j + n2 * (ch + (long long)r1 * aa)], Hbi[ga + bz * (j + (long long)n2 * aa)], a);
+            T1[e_] = a;
+        }
+        __syncthreads();
+        WG_FOR((long long)ba * n1 * r1) {
+            long long t = e_; const int be = t % ba; t /= ba; const int ii = t % n1; const int ch = (int)(t / n1);
+            double a = 0.0;
+            for (int ga = 0; ga < bz; ++ga) a = fma(bb[ii + n1 * (be + (long long)ba * ga)], T1[ga + (long long)bz * ch], a);
+            Hbo[e_] = a;
+        }
+        __syncthreads();
+    };
+    // two-site solve at sites i, i+1: V (n1, r_i, n2, r_{i+2}) column-major in Pb
+    auto ksolve = [&](int i, int& a_out, int& b_out) -> bool {
+        const int n1 = uni32(P.x.dims[i]), n2 = uni32(P.x.dims[i + 1]);
+        const int rl = uni32((int)xr[i]), rr = uni32((int)xr[i + 2]);
+        const int Rz = uni32((int)P.A.rks[i + 1]), bz = uni32((int)br_[i + 1]);
+        const double *Gi = GP(i), *Gbi = GBP(i), *Hi = HP(i), *Hbi = HBP(i);
+        const int na = n1 * rl, nb = n2 * rr, N = na * nb;
+        a_out = na; b_out = nb;
+        WG_FOR((long long)N * N) {
+            const int row = (int)(e_ % N), col = (int)(e_ / N);
+            const int ab = row % na, cd = row / na, ef = col % na, gh = col / na;
+            double a = 0.0;
+            for (int z = 0; z < Rz; ++z) a = fma(Gi[ab + (long long)na * (ef + (long long)na * z)], Hi[z + Rz * (cd + (long long)nb * gh)], a);
+            K[e_] = a;
+        }
+        WG_FOR(N) {
+            const int ab = (int)(e_ % na), cd = (int)(e_ / na);
+            double a = 0.0;
+            for (int z = 0; z < bz; ++z) a = fma(Gbi[ab + (long long)na * z], Hbi[z + (long long)bz * cd], a);
+            Pb[e_] = a;
+        }
+        __syncthreads();
+        return wg_lu_solve(N, K, Pb, piv, red, S.iflag, lds) == 0;
+    };
+
+    // ---- initial environments (mals.jl:255-265) ----
+    {
+        const AlsSite s = SITE(0);
+        WG_FOR((long long)s.n * s.n * s.Rr) GP(0)[e_] = AC(0)[e_];
+        WG_FOR((long long)s.n * s.br) GBP(0)[e_] = BC(0)[e_];
+        // H_{d-2}[z, j, 1, k, 1] = A_d[j, k, z, 1] ; Hb_{d-2}[ga, j, 1] = b_d[j, ga, 1]
+        const int n = uni32(P.x.dims[d - 1]), Rz = uni32((int)P.A.rks[d - 1]), bz = uni32((int)br_[d - 1]);
+        WG_FOR((long long)Rz * n * n) {
+            long long t = e_; const int z = t % Rz; t /= Rz; const int j = t % n; const int k = (int)(t / n);
+            HP(d - 2)[e_] = AC(d - 1)[j + n * (k + (long long)n * z)];
+        }
+        WG_FOR((long long)bz * n) { const int ga = (int)(e_ % bz), j = (int)(e_ / bz); HBP(d - 2)[e_] = BC(d - 1)[j + (long long)n * ga]; }
+        __syncthreads();
+    }
+    for (int i = d - 2; i >= 1; --i) update_H(i);
+    int status = 0;
+    for (int dir = 0; dir < 2 && !status; ++dir) {
+        for (int step = 0; step < d - 1 && !status; ++step) {
+            const int i = dir == 0 ? step : d - 2 - step;
+            int na, nb;
+            if (!ksolve(i, na, nb)) { status = 3; break; }
+            const int n2 = uni32(P.x.dims[i + 1]);
+            const int cap = min((int)P.x.cap[i + 1], Q.rmax);
+            double* xi = XC(i);
+            double* xn = XC(i + 1);
+            int r;
+            if (dir == 0)        // right_core_move_mals: x_i <- U, x_{i+1} <- S V'
+                r = wg_hsvd_step(Q.C, b, S, mkview(Pb, plain(1), plain(na)), na, nb, M2, 2, n2, 0, xi, xn, Q.tol, (int)P.x.cap[i + 1], lds, 1, Q.rmax);
+            else                 // left_core_move_mals: x_{i+1} <- V', x_i <- U S  (the step on the transposed view)
+                r = wg_hsvd_step(Q.C, b, S, mkview(Pb, plain(na), plain(1)), nb, na, M2, 1, n2, 0, xn, xi, Q.tol, (int)P.x.cap[i + 1], lds, 1, Q.rmax);
+            (void)cap;
+            if (r < 0) { status = 2; break; }
+            if (tid == 0) xr[i + 1] = r;
+            __syncthreads();
+            if (dir == 0) als_update_G(E, i);
+            else if (i > 0) update_H(i);
+        }
+    }
+    if (status && tid == 0) P.status[b] = status;
+}
 #undef XC
 #undef BC
 #undef AC
@@ -371,4 +554,3 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
 #undef HBP
 #undef SITE
 #undef WG_FOR
-}

@@ -146,6 +146,8 @@ int ttn_init(int device) {
     // the compress / orthogonalize kernels use more than the default 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compress), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(COMPRESS_LDS_BYTES)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mals_linsolve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_linsolve), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ttv_decomp), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1056,6 +1058,90 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
             for (int i = d - 1; i >= 1; --i) { ot[i] = 1; ot[i - 1] = 0; }
         }
     }
+    return TTN_OK;
+}
+
+// ---- mals_linsolve -----------------------------------------------------------------------------------------------
+int ttn_mals_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t rmax) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!A || !b || !x0 || !x) return fail(TTN_ERR_ARG, "null handle");
+    if (tol < 0.0 || rmax < 1) return fail(TTN_ERR_ARG, "bad tol / rmax");
+    if (!same_dims(A->dims, b->dims) || !same_dims(b->dims, x0->dims) || !same_dims(x0->dims, x->dims)) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    if (b->batch != x0->batch || x->batch != x0->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
+    const int d = x0->d;
+    if (d < 2) return fail(TTN_ERR_UNSUPPORTED, "ttn_mals_linsolve: needs at least two sites");
+    int rc = ttn_orthogonalize(x0, 1, x);                  // mals.jl:252 (checks x's capacity against the start ranks)
+    if (rc) return rc;
+    const std::vector<int64_t>& c = x->cap;
+    const std::vector<int64_t>& R = A->rks;
+    const std::vector<int64_t>& rb = b->bound;
+    auto mx = [](long long a_, long long b_) { return a_ > b_ ? a_ : b_; };
+    std::vector<long long> off(4 * d, 0);
+    long long cur = 0, Nmax = 1, mmax = 1, t1 = 1, t2 = 1;
+    for (int i = 0; i < d; ++i) {
+        const long long n = x0->dims[i];
+        off[i] = cur; cur += n * c[i] * n * c[i] * R[i + 1];
+        off[d + i] = cur; cur += n * c[i] * rb[i + 1];
+        mmax = mx(mmax, mx(n * c[i], n * c[i + 1]));
+        t1 = mx(t1, n * c[i] * c[i + 1] * mx(R[i], R[i + 1]));
+        t1 = mx(t1, mx(c[i + 1] * rb[i + 1], c[i] * rb[i + 1]));
+        t2 = mx(t2, c[i + 1] * c[i + 1] * R[i + 1]);
+        if (i + 1 < d) {
+            const long long n2 = x0->dims[i + 1];
+            off[2 * d + i] = cur; cur += R[i + 1] * n2 * n2 * c[i + 2] * c[i + 2];
+            off[3 * d + i] = cur; cur += rb[i + 1] * n2 * c[i + 2];
+            Nmax = mx(Nmax, n * c[i] * n2 * c[i + 2]);
+            t1 = mx(t1, mx(R[i + 1] * n2 * c[i + 2] * c[i + 1], rb[i + 1] * c[i + 1]));
+            t2 = mx(t2, R[i + 1] * c[i + 1] * c[i + 1]);
+        }
+    }
+    if (Nmax > 2048) return fail(TTN_ERR_UNSUPPORTED, "ttn_mals_linsolve: two-site systems above 2048 unknowns (n_i cap_i n_{i+1} cap_{i+2}) are not supported; lower the capacity of x");
+    const long long pmax = std::min<long long>(mmax, 256), qmax = mmax;
+    MalsArgs Q;
+    memset(&Q, 0, sizeof(Q));
+    AlsArgs& P = Q.L;
+    P.offK = cur; cur += Nmax * Nmax;
+    P.offPb = cur; cur += Nmax;
+    P.offPiv = cur; cur += Nmax / 2 + 8;
+    P.offT1 = cur; cur += t1;
+    P.offT2 = cur; cur += t2;
+    P.offVb = cur; cur += QR_NB * qmax;
+    P.offWb = cur; cur += QR_NB * qmax;
+    Q.offM2 = cur; cur += Nmax;
+    Q.offXg = cur; cur += pmax * pmax;
+    Q.offUs = cur; cur += pmax * pmax;
+    Q.offSig = cur; cur += 4 * pmax + 64;
+    const long long per_train = cur;
+    const int batch = x->batch;
+    static std::vector<long long> h_off;
+    HIPCHK(hipStreamSynchronize(g_stream));
+    rc = ensure_scratch(sizeof(double) * (size_t)per_train * batch + sizeof(long long) * (size_t)(4 * d) + 64);
+    if (rc) return rc;
+    rc = ensure_batch_bufs(batch);
+    if (rc) return rc;
+    double* base = (double*)g_scratch;
+    long long* d_tab = (long long*)(base + (size_t)per_train * batch);
+    h_off = off;
+    HIPCHK(hipMemcpyAsync(d_tab, h_off.data(), sizeof(long long) * h_off.size(), hipMemcpyHostToDevice, g_stream));
+    P.A = A->dev(); P.b = b->dev(); P.x = x->dev();
+    P.scratch = base; P.scratch_stride = per_train;
+    P.off = d_tab;
+    P.status = g_status;
+    Q.C.status = g_status;
+    Q.C.sweep_stats = g_status + batch;
+    Q.C.pmax = (int)pmax; Q.C.qmax = (int)qmax;
+    { const char* e = getenv("TTN_JTOL"); Q.C.jtol_mult = e ? atof(e) : 1.0; }
+    { const char* e = getenv("TTN_JNEG"); Q.C.jneg_mult = e ? atof(e) : 1.0; }
+    Q.tol = tol;
+    Q.rmax = (int)std::min<int64_t>(rmax, 1 << 30);
+    Q.pmax = (int)pmax; Q.qmax = (int)qmax;
+    hipLaunchKernelGGL(k_mals_linsolve, dim3(batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, Q);
+    HIPCHK(hipGetLastError());
+    for (int m = 1; m < d; ++m) x->bound[m] = std::min<int64_t>(x->cap[m], rmax);
+    x->bound[0] = 1; x->bound[d] = 1;
+    for (int bb = 0; bb < batch; ++bb)
+        for (int k = 0; k < d; ++k) x->ot[(size_t)bb * d + k] = (k == 0) ? 0 : 1;        // after the backward half sweep (mals.jl:116-117)
     return TTN_OK;
 }
 

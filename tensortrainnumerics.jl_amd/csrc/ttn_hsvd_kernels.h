@@ -21,9 +21,16 @@ struct HsvdArgs {
 //   left  (sites i < index): A[(al + rl*x), col]; core[x, al, j] = W[al + rl*x, j]; remainder (r x b) column-major, ld = r
 //   right (sites i > index): A[(x + n*be), row] (the transposed unfolding); core[x, j, be] = W[x + n*be, j];
 //                            remainder[j, row] stored as the column-major (rows x r) matrix U S of the reference
+// `layout` 2 / 3 are the two-site core moves of mals_linsolve (src/solvers/mals.jl:94-146) on V = (n1 r_l) x (n2 r_r):
+//   2 (right move): core = x_i (n1, r_l, r) <- U, contiguous; remainder S V' -> x_{i+1}[x, j, c] = (S V')[j, x + n c]   (n = n2)
+//   3 (left move, called on the TRANSPOSED view): core = x_{i+1}[x, j, c] <- V'[j, x + n c]; remainder (U S) -> x_i, contiguous
+// `rule` 0: r = count(s >= tol) (absolute); 1: sv_trunc (mals.jl:42-56: drop the tail while its weight stays below
+// tol * ||s||^2, keep the value that crossed the line) clamped to `rclamp`.
 // Returns r (>= 1), or -1 if r exceeds `cap` (nothing written).
 __device__ __noinline__ int wg_hsvd_step(const CompressArgs& P, int b, const BondCtx& S, View Av, int a, int bcols, double* M2,
-                                         bool left, int n, int rfix, double* core, double* rem, double tol, int cap, double* lds) {
+                                         int layout, int n, int rfix, double* core, double* rem, double tol, int cap, double* lds,
+                                         int rule = 0, int rclamp = 1 << 30) {
+    const bool left = layout == 0;
     a = uni32(a); bcols = uni32(bcols); n = uni32(n); rfix = uni32(rfix); cap = uni32(cap);
     Av = uniView(Av); M2 = unip(M2); core = unip(core); rem = unip(rem); lds = unip(lds);
     const int tid = threadIdx.x;
@@ -59,7 +66,19 @@ __device__ __noinline__ int wg_hsvd_step(const CompressArgs& P, int b, const Bon
     // rank: count(s >= tol), absolute (src/tt_tools.jl:203, :224); an all-zero remainder keeps one (zero) direction
     if (tid == 0) {
         int r = 0;
-        for (int i = 0; i < p; ++i) r += (S.sigs[i] * s0 >= tol) ? 1 : 0;
+        if (rule == 0) { for (int i = 0; i < p; ++i) r += (S.sigs[i] * s0 >= tol) ? 1 : 0; }
+        else {
+            r = p;
+            if (tol != 0.0) {
+                double norm2 = 0.0, weight = 0.0;
+                for (int i = 0; i < p; ++i) { const double sv = S.sigs[i] * s0; norm2 = fma(sv, sv, norm2); }
+                int i = 0;
+                while (i < p && weight < tol * norm2) { const double sv = S.sigs[p - i - 1] * s0; weight = fma(sv, sv, weight); ++i; }
+                r = p - i + 1;
+                if (r > p) r = p;
+            }
+            if (r > rclamp) r = rclamp;
+        }
         S.iflag[1] = r < 1 ? 1 : r;
     }
     __syncthreads();
@@ -77,9 +96,11 @@ __device__ __noinline__ int wg_hsvd_step(const CompressArgs& P, int b, const Bon
     __syncthreads();
     // output views
     const View coreV = left ? mkview(core, Idx{rfix, (long long)n, 1}, plain((long long)n * rfix))          // (a x r): row al + rl*x
-                            : mkview(core, Idx{n, 1, (long long)n * r}, plain(n));                          // (a x r): row x + n*be
+                     : (layout == 2) ? mkview(core, plain(1), plain(a))                                     // (a x r) contiguous
+                                     : mkview(core, Idx{n, 1, (long long)n * r}, plain(n));                 // (a x r): row x + n*be
     const View remV = left ? mkview(rem, plain(1), plain(r))                                                // (r x b) column-major
-                           : mkview(rem, plain(bcols), plain(1));                                           // (r x rows): U S column-major
+                    : (layout == 2) ? mkview(rem, plain(n), Idx{n, 1, (long long)n * r})                    // x_{i+1}[x, j, c]
+                                    : mkview(rem, plain(bcols), plain(1));                                  // (r x rows): U S column-major
     if (!tall) {
         // W = short-side vectors; remainder = W^T A
         for (int e = tid; e < p * r; e += TTN_WG) {
@@ -143,7 +164,7 @@ __global__ void __launch_bounds__(TTN_WG) k_ttv_decomp(HsvdArgs H) {
         const int a = rleft * n;
         const int bc = (int)(len / a);
         double* core = T.data + (long long)b * T.stride + T.off[i];
-        const int r = wg_hsvd_step(P, b, S, mkview(cur, plain(1), plain(a)), a, bc, M2, true, n, rleft, core, nxt, H.tol, (int)T.cap[i + 1], lds);
+        const int r = wg_hsvd_step(P, b, S, mkview(cur, plain(1), plain(a)), a, bc, M2, 0, n, rleft, core, nxt, H.tol, (int)T.cap[i + 1], lds);
         if (r < 0) { alive = false; break; }
         if (tid == 0) rks[i + 1] = r;
         rleft = r;
@@ -159,7 +180,7 @@ __global__ void __launch_bounds__(TTN_WG) k_ttv_decomp(HsvdArgs H) {
         const int rows = (int)(len / a);
         double* core = T.data + (long long)b * T.stride + T.off[i];
         // the reference's unfolding is (rows x a) column-major = this a x rows matrix row-major
-        const int r = wg_hsvd_step(P, b, S, mkview(cur, plain(rows), plain(1)), a, rows, M2, false, n, rright, core, nxt, H.tol, (int)T.cap[i], lds);
+        const int r = wg_hsvd_step(P, b, S, mkview(cur, plain(rows), plain(1)), a, rows, M2, 1, n, rright, core, nxt, H.tol, (int)T.cap[i], lds);
         if (r < 0) { alive = false; break; }
         if (tid == 0) rks[i] = r;
         rright = r;

@@ -415,3 +415,39 @@ def als_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, sweep_count: in
     als_linsolve_(dA, db, dx0, dx, sweep_count)
     D.compress_status(dx)
     return dx.download(0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mals_linsolve (src/solvers/mals.jl:240-312) — csrc/ttn_als_kernels.h (k_mals_linsolve)
+# ---------------------------------------------------------------------------------------------------------------------
+def mals_linsolve_(A: DeviceTTO, b: DeviceTT, x0: DeviceTT, x: DeviceTT, tol: float = 1.0e-12, rmax: int = 2 ** 30) -> DeviceTT:
+    """x_b = mals_linsolve(A, b_b, x0_b; tol, rmax) for every train of the batch; x's capacity bounds the adapted ranks."""
+    _lib.check(_lib.lib().ttn_mals_linsolve(A.h, b.h, x0.h, x.h, float(tol), int(min(rmax, 2 ** 30))))
+    return x
+
+
+def mals_capacity(dims, start_rks, rmax: int, limit: int = 2048):
+    """Rank capacity for the result handle: min(rmax, prod(dims[:k]), prod(dims[k:])) like the reference's buffers
+    (mals.jl:258, :23), at least the start ranks, lowered uniformly until every two-site system fits the device limit."""
+    d = len(dims)
+    full = [1] + [min(int(rmax), int(math.prod(dims[:k])), int(math.prod(dims[k:]))) for k in range(1, d)] + [1]
+    cut = max(full)
+    while True:
+        cap = [max(min(f, cut), int(s)) for f, s in zip(full, start_rks)]
+        worst = max(dims[i] * cap[i] * dims[i + 1] * cap[i + 2] for i in range(d - 1)) if d > 1 else 1
+        if worst <= limit or cut <= 1:
+            return cap
+        cut -= 1
+
+
+def mals_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1.0e-12, rmax: int | None = None) -> TTvector:
+    """Host-level form for one right-hand side.  rmax defaults to round(sqrt(prod(dims))) like the reference (mals.jl:244)."""
+    if rmax is None:
+        rmax = int(round(math.sqrt(math.prod(tt_start.ttv_dims))))
+    dA = DeviceTTO(A)
+    db, dx0 = DeviceTT.from_host(b), DeviceTT.from_host(tt_start)
+    dx = DeviceTT(tt_start.ttv_dims, mals_capacity(tt_start.ttv_dims, tt_start.ttv_rks, rmax))
+    mals_linsolve_(dA, db, dx0, dx, tol, rmax)
+    D.compress_status(dx)
+    dx.max_ranks()
+    return dx.download(0)

@@ -58,3 +58,24 @@ got = to_oracle(dx.download(0))
 res = tt_norm_stable(O.sub(O.apply(A, got), b)) / tt_norm_stable(b)
 print(f"als_linsolve 2D Laplace {bits}+{bits} bits rank {rank}, {sweeps} half sweeps: device {tm.ms:.1f} ms for {B} systems ({tm.ms / B:.2f} ms each);"
       f" cpu oracle {t_cpu * 1e3:.1f} ms each; rel diff {tt_rel_diff(got, ref):.1e}; residual {res:.2e}")
+
+# mals_linsolve on the same problem, start ranks of the right-hand side like examples/Laplace_pde.jl:24-27
+x0m = O.rand_tt((2,) * N, b.ttv_rks, rng)
+rmax = 16
+cap = T.solvers.mals_capacity((2,) * N, x0m.ttv_rks, rmax)
+dbm = T.DeviceTT.from_host(to_product(b), batch=B)
+dx0m = T.DeviceTT.from_host(to_product(x0m), batch=B)
+dxm = T.DeviceTT((2,) * N, cap, batch=B)
+T.solvers.mals_linsolve_(dA, dbm, dx0m, dxm, 1e-12, rmax)
+T.device.compress_status(dxm)
+with T.StreamTimer() as tm:
+    T.solvers.mals_linsolve_(dA, dbm, dx0m, dxm, 1e-12, rmax)
+T.device.compress_status(dxm)
+t0 = time.time()
+refm = O.mals_linsolve(A, b, x0m, tol=1e-12, rmax=rmax)
+t_cpu = time.time() - t0
+gotm = to_oracle(dxm.download(0))
+res = tt_norm_stable(O.sub(O.apply(A, gotm), b)) / tt_norm_stable(b)
+resc = tt_norm_stable(O.sub(O.apply(A, refm), b)) / tt_norm_stable(b)
+print(f"mals_linsolve (tol 1e-12, rmax {rmax}): ranks {gotm.ttv_rks} (cpu {refm.ttv_rks}); device {tm.ms:.1f} ms for {B} systems; cpu oracle {t_cpu * 1e3:.1f} ms each;"
+      f" residual {res:.2e} (cpu {resc:.2e})")

@@ -390,3 +390,33 @@ def test_als_linsolve_reference_assertions():
     A, b, x0 = spd(d, 3.0), O.rand_tt((2,) * d, 3, rng), O.rand_tt((2,) * d, [1, 2, 4, 4, 2, 1], rng)
     dense = np.linalg.solve(O.qtto_to_matrix(A), O.qtt_to_vector(b))
     assert np.max(np.abs(O.qtt_to_vector(O.als_linsolve(A, b, x0, sweep_count=2)) - dense)) <= 1e-11 * np.max(np.abs(dense))
+
+
+def test_mals_linsolve_reference_assertions():
+    """test/test_mals.jl:19-77 with NumPy inputs, plus exactness against the dense solve when the ranks allow it."""
+    rng = np.random.default_rng(5678)
+
+    def spd(d, shift):
+        return O.tto_add(O.Delta(d), O.tto_scale(shift, O.id_tto(d)))
+
+    def resid(A, x, b):
+        return O.norm(O.sub(O.apply(A, x), b)) / max(O.norm(b), np.finfo(float).eps)
+
+    d = 4
+    b, x0 = O.rand_tt((2,) * d, [1, 2, 2, 2, 1], rng), O.rand_tt((2,) * d, [1, 2, 2, 2, 1], rng)
+    x = O.mals_linsolve(spd(d, 3.0), b, x0)
+    assert x.N == d and x.ttv_dims == (2,) * d
+    assert resid(spd(d, 10.0), O.mals_linsolve(spd(d, 10.0), b, x0, tol=1e-10, rmax=8), b) < 0.5
+    b1, x1 = O.rand_tt((2,) * d, [1] * 5, rng), O.rand_tt((2,) * d, [1] * 5, rng)
+    assert resid(O.id_tto(d), O.mals_linsolve(O.id_tto(d), b1, x1, tol=1e-12, rmax=4), b1) < 0.05
+    assert max(O.mals_linsolve(spd(d, 5.0), b, x1, tol=1e-10, rmax=4).ttv_rks) <= 4
+    xl, xt = O.mals_linsolve(spd(d, 3.0), b, x0, tol=1e-2, rmax=8), O.mals_linsolve(spd(d, 3.0), b, x0, tol=0.0, rmax=8)
+    assert max(xl.ttv_rks) <= max(xt.ttv_rks) + 2
+    # hand evaluation of mals.jl:47-54: the tail is summed until its weight reaches tol * ||s||^2; the value that crossed is kept
+    assert list(O.sv_trunc(np.array([3.0, 2.0, 1e-9, 1e-10]), 1e-12)) == [3.0, 2.0]
+    assert list(O.sv_trunc(np.array([3.0, 2.0, 1.0]), 0.2)) == [3.0, 2.0]          # 1 < 2.8, 1 + 4 >= 2.8 -> i = 2 -> s[1:2]
+    assert list(O.sv_trunc(np.array([3.0, 2.0, 1.0]), 0.0)) == [3.0, 2.0, 1.0]
+    d = 6
+    A, b, x0 = spd(d, 2.0), O.rand_tt((2,) * d, 2, rng), O.rand_tt((2,) * d, 2, rng)
+    dense = np.linalg.solve(O.qtto_to_matrix(A), O.qtt_to_vector(b))
+    assert np.max(np.abs(O.qtt_to_vector(O.mals_linsolve(A, b, x0, tol=1e-14, rmax=64)) - dense)) <= 1e-11 * np.max(np.abs(dense))
