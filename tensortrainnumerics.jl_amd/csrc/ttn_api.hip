@@ -6,6 +6,7 @@
 #include "ttn_ortho_kernels.h"
 #include "ttn_hsvd_kernels.h"
 #include "ttn_als_kernels.h"
+#include "ttn_eig_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -146,6 +147,8 @@ int ttn_init(int device) {
     // the compress / orthogonalize kernels use more than the default 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compress), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(COMPRESS_LDS_BYTES)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_selftest_eig128), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mals_linsolve), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_linsolve), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1281,6 +1284,33 @@ int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const do
     HIPCHK(hipMemcpyAsync(C, dC, sizeof(double) * m * n, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     hipFree(dA); hipFree(dB); hipFree(dC);
+    return TTN_OK;
+}
+
+// self-test of the 128 x 128 symmetric eigensolver of the Gram route: G (host, column-major) -> sig[nev] = sqrt(eigenvalues)
+// descending, X[128 * r] = sqrt(lam_j) u_j, cycles (s_memtime ticks) and the return code of the device routine
+int ttn_selftest_eig128(const double* G, int64_t r, int64_t nev, double* sig, double* X, int64_t* ticks_rc) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!G || !sig || !X || r < 1 || r > 64 || nev < r || nev > 128) return fail(TTN_ERR_ARG, "bad argument");
+    double *dG = nullptr, *dV = nullptr, *dS = nullptr, *dX = nullptr;
+    long long* dC = nullptr;
+    HIPCHK(hipMalloc((void**)&dG, sizeof(double) * 128 * 128));
+    HIPCHK(hipMalloc((void**)&dV, sizeof(double) * 128 * 128));
+    HIPCHK(hipMalloc((void**)&dS, sizeof(double) * 128));
+    HIPCHK(hipMalloc((void**)&dX, sizeof(double) * 128 * 64));
+    HIPCHK(hipMalloc((void**)&dC, sizeof(long long) * 8));
+    HIPCHK(hipMemcpyAsync(dG, G, sizeof(double) * 128 * 128, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemsetAsync(dX, 0, sizeof(double) * 128 * 64, g_stream));
+    hipLaunchKernelGGL(k_selftest_eig128, dim3(1), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, dG, dV, (int)r, (int)nev, dS, dX, dC);
+    HIPCHK(hipGetLastError());
+    long long hc[8] = {0};
+    HIPCHK(hipMemcpyAsync(sig, dS, sizeof(double) * nev, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(X, dX, sizeof(double) * 128 * r, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(hc, dC, sizeof(long long) * 8, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    if (ticks_rc) { ticks_rc[0] = hc[0]; ticks_rc[1] = hc[1]; for (int t = 2; t < 6; ++t) ticks_rc[t] = hc[t + 1] - hc[t]; }   // tridiag, bisect, twisted, back-transform
+    hipFree(dG); hipFree(dV); hipFree(dS); hipFree(dX); hipFree(dC);
     return TTN_OK;
 }
 

@@ -1659,6 +1659,9 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
 // src/qtt_tools.jl:660-695; both cores have the same physical dimension here): the merged matrix takes its row index from
 // (left rank, physical index of core k+1) and its column index from (physical index of core k, right rank), and the factors
 // are U and S*Vt instead of U sqrt(S), sqrt(S) Vt.  Only route H is used (the swapped matrices are rank deficient by design).
+// symmetric eigensolver of the Gram route (ttn_eig_kernels.h, included after this header by the translation unit)
+__device__ int wg_eig128(const double* Gg, double* Vst, int r, int nev, double* sig, double* lds, int* iwork, double* dwork, long long* prof);
+
 struct BondIO {
     double *ck, *ck1;            // the two cores (slots)
     int n1, n2, Dl, rm, Dr;      // physical dimensions and the three ranks
@@ -1876,10 +1879,24 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         const bool lq_in_lds = (long long)p * q <= GEMM_LDS_DOUBLES || GEMM_LDS_DOUBLES / p >= 2 * p;     // whole, or TSQR chunks (wg_lq_blocked)
         for (int attempt = (SWAP == 0 && P.fast && need_lq && x_in_lds && p >= 2 && !lq_in_lds) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
             bool ok = true;
+            bool use_eig = false;
             if (attempt == 1) {
                 // =========================== route G: L = chol(M M^T) ===========================
                 wg_gemm(p, p, q, Mv, tview(Mv), mkview(S.Ga, plain(1), plain(128)), inv_s0 * inv_s0, 0.0, lds);
                 PROF_MARK(7)
+                // p = 128 with at most 64 vectors kept (the L->R steps of the benchmark sweep): eigen-decomposition of the Gram
+                // matrix itself — tridiagonalisation, bisection, twisted factorisations (ttn_eig_kernels.h) — instead of
+                // Cholesky + Jacobi on L; same outputs (sigs, perm, X = sigma_j u_j in LDS), same a-posteriori check below
+                use_eig = (p == 128) && !(P.fast & 2) && P.max_bond <= 64;
+                if (use_eig) {
+                    const int r0 = (int)P.max_bond;
+                    const int nev = (P.truncerr > 0.0 || (P.sv_out && step < P.sv_steps)) ? 128 : r0;
+                    ok = wg_eig128(S.Ga, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64, nullptr) == 0;
+                    for (int j = tid; j < 128; j += TTN_WG) { S.perm[j] = j; if (j >= nev) S.sigs[j] = 0.0; }
+                    if (tid == 0) S.scal[0] = P.jneg_mult * P.jneg_mult * 128.0 * DBL_EPSILON * DBL_EPSILON * S.sigs[0] * S.sigs[0];
+                    __syncthreads();
+                    PROF_MARK(11)
+                } else {
                 for (int e = tid; e < p * 128; e += TTN_WG) if ((e & 127) < p) S.ldsX[e] = S.Ga[e];
                 __syncthreads();
                 ok = wg_chol_lds128(p, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
@@ -1892,6 +1909,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 for (int e = tid; e < p * 128; e += TTN_WG) if ((e & 127) >= p) S.ldsX[e] = 0.0;      // zero row padding for the Jacobi
                 __syncthreads();
                 PROF_MARK(11)
+                }
             } else {
                 // =========================== route H: Householder LQ ===========================
                 if (need_lq) {
@@ -1934,7 +1952,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 PROF_MARK(2)
             }
             int nsw = 0;
-            if (ok) {
+            if (ok && !(attempt == 1 && use_eig)) {
                 nsw = uni32(wg_svd_cols(P, S, p, X, ldx, x_in_lds));
                 nsw_total += (nsw < 0 ? -nsw : nsw);
                 if (attempt == 1) ok = nsw > 0;
