@@ -13,6 +13,13 @@
 #include "ttn_dense_kernels.h"
 
 #define EIG_N 128
+// a += (lane J of the caller's row of 16 lanes of w) * s : the DPP form of the fp64 multiply-add broadcasts a lane of each row for
+// free (row_newbcast is the one DPP control 64-bit VALU ops take on gfx90a+), which replaces an LDS broadcast read per operand
+template <int J>
+__device__ __forceinline__ void fmac_bcast(double& a, double w, double s_) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(w), "v"(s_), "n"(J));
+}
+#define EIG_BCAST16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 // LDS map (doubles) inside the 128*128 + 512 Jacobi/GEMM image `L`:
 //   [0, 16384)            phase 1: vL, wL, xcol (3 x 128), part (8 x 128)   | phase 3: D+ then D- ([row][lane], 2 x 8192)
 //                         phase 4: partial dot products (2 x 16 x 64), then the output image X (ld 128)
@@ -41,7 +48,7 @@ __device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double
         // spending issue slots of the shared SIMDs on redundant copies of this scalar-ish code
         if (wave == 0) {
             const double x0 = (lane > k) ? xcol[lane] : 0.0, x1 = (lane + 64 > k) ? xcol[lane + 64] : 0.0;
-            const double s2 = wave_sum(fma(x0, x0, x1 * x1));
+            const double s2 = wave64_sum_fast(fma(x0, x0, x1 * x1));
             const double xk1 = xcol[k + 1];
             const double alpha = (s2 > 0.0) ? -copysign(sqrt(s2), xk1) : 0.0;
             const double den = s2 - alpha * xk1;                   // = v'v / 2
@@ -52,10 +59,14 @@ __device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double
             if (lane == 0) { dg[k] = xcol[k]; e[k] = alpha; beta[k] = bta; }
         }
         __syncthreads();
-        // p = A v (partial over the thread's 16 columns)
+        // p = A v (partial over the thread's 16 columns): lane l of a row of 16 lanes holds v[16c + l], the DPP multiply-add
+        // broadcasts it — 2 LDS reads per thread and step instead of 48
+        const double vreg = vL[16 * c + (lane & 15)];
         double pp = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) pp = fma(a[j], vL[16 * c + j], pp);
+        asm volatile("s_nop 1");
+#define EIG_MV(j) fmac_bcast<j>(pp, vreg, a[j]);
+        EIG_BCAST16(EIG_MV)
+#undef EIG_MV
         part[c * 128 + i] = pp;
         __syncthreads();
         if (wave == 0) {
@@ -64,14 +75,17 @@ __device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) { p0 += part[cc * 128 + lane]; p1 += part[cc * 128 + lane + 64]; }
             p0 *= bta; p1 *= bta;
-            const double Kc = 0.5 * bta * wave_sum(fma(p0, v0, p1 * v1));
+            const double Kc = 0.5 * bta * wave64_sum_fast(fma(p0, v0, p1 * v1));
             wL[lane] = fma(-Kc, v0, p0); wL[lane + 64] = fma(-Kc, v1, p1);
         }
         __syncthreads();
         // A -= v w' + w v'
-        const double vi = vL[i], wi = wL[i];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = fma(-vi, wL[16 * c + j], fma(-wi, vL[16 * c + j], a[j]));
+        const double wreg = wL[16 * c + (lane & 15)];
+        const double nvi = -vL[i], nwi = -wL[i];
+        asm volatile("s_nop 1");
+#define EIG_UP(j) fmac_bcast<j>(a[j], wreg, nvi); fmac_bcast<j>(a[j], vreg, nwi);
+        EIG_BCAST16(EIG_UP)
+#undef EIG_UP
     }
     // the last 2 x 2 block
     if (i == EIG_N - 2 && c == 7) { dg[EIG_N - 2] = a[14]; e[EIG_N - 2] = a[15]; }
@@ -79,14 +93,25 @@ __device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double
     __syncthreads();
 }
 
-// number of eigenvalues of the tridiagonal (dg, e2 = e^2) below x
-__device__ inline int sturm_count(const lds_f64* dg, const lds_f64* e2, double x, double pivmin) {
-    double q = dg[0] - x;
-    int cnt = (q < 0.0) ? 1 : 0;
-    for (int i = 1; i < EIG_N; ++i) {
-        if (fabs(q) < pivmin) q = -pivmin;
-        q = fma(-e2[i - 1], fast_rcp(q), dg[i] - x);
-        cnt += (q < 0.0) ? 1 : 0;
+// number of eigenvalues of the tridiagonal below x.  de = LDS array of pairs (d_i, e_{i-1}^2) (e_{-1} = 0): the recurrence is
+// a dependent chain, so the operands of 8 steps are fetched together (4 ds_read_b128 each for d and e^2 would be the naive
+// form; pairs make it one b128 per step) and the LDS latency is paid once per chunk
+__device__ inline int sturm_count(const lds_f64* de, double x, double pivmin) {
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    typedef __attribute__((address_space(3))) d2 lds_d2;
+    const lds_d2* p2 = (const lds_d2*)de;
+    double q = 1.0;                                               // e_{-1}^2 = 0: the first step gives d_0 - x
+    int cnt = 0;
+    for (int i0 = 0; i0 < EIG_N; i0 += 8) {
+        d2 v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = p2[i0 + t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (fabs(q) < pivmin) q = -pivmin;
+            q = fma(-v[t].y, fast_rcp(q), v[t].x - x);
+            cnt += (q < 0.0) ? 1 : 0;
+        }
     }
     return cnt;
 }
@@ -98,7 +123,8 @@ __device__ void wg_bisect128(int nev, double* lds) {
     lds_f64 *dg = L + EIG_TAIL, *e = dg + 128, *lam = dg + 256;
     lds_f64* e2 = L;                                             // phase-1 work area is free
     const int tid = threadIdx.x;
-    for (int t = tid; t < EIG_N; t += TTN_WG) e2[t] = (t < EIG_N - 1) ? e[t] * e[t] : 0.0;
+    lds_f64* de = L + 256;                                        // pairs (d_i, e_{i-1}^2)
+    for (int t = tid; t < EIG_N; t += TTN_WG) { e2[t] = (t < EIG_N - 1) ? e[t] * e[t] : 0.0; de[2 * t] = dg[t]; de[2 * t + 1] = (t > 0) ? e[t - 1] * e[t - 1] : 0.0; }
     __syncthreads();
     // Gershgorin interval and the pivot floor: wave 0, results through LDS (e2[128..130])
     if (tid < 64) {
@@ -128,7 +154,9 @@ __device__ void wg_bisect128(int nev, double* lds) {
             const bool done = !(wdt > 2.0 * DBL_EPSILON * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin);
             if (__syncthreads_and(done || !act)) break;
             const double x = lo + wdt * ((double)(sub + 1) / (double)(TL + 1));
-            const int cnt = sturm_count(dg, e2, x, pivmin);
+            // waves whose groups are all beyond nev skip the count (wave-uniform branch): they would only compete for issue slots
+            const bool wave_act = g0 + (tid & ~63) / TL < nev;
+            const int cnt = wave_act ? sturm_count(de, x, pivmin) : 0;
             // nf = number of section points with count <= jasc (monotone in sub): the eigenvalue lies right of point nf-1
             int nf = (cnt <= jasc) ? 1 : 0;
 #pragma unroll
@@ -144,61 +172,80 @@ __device__ void wg_bisect128(int nev, double* lds) {
     __syncthreads();
 }
 
-// ---- 3. eigenvectors of lam[0..r-1] by twisted factorisations; z (unnormalised) stays split over the D+ / D- arrays,
-//         twist index and 1/||z|| per vector in tw[], zn[] ----
-__device__ void wg_twisted128(int r, double* lds, int* tw /*LDS r ints*/, lds_f64* zn /*LDS r*/) {
+// ---- 3. eigenvectors of lam[0..r-1] (r <= 64) by twisted factorisations; z (unnormalised) stays split over the D+ / D- arrays,
+//         twist index and 1/||z|| per vector in tw[], zn[].  One lane per vector; wave 0 runs the top-down recurrences (D+, then
+//         z above the twist), wave 1 the bottom-up ones (D-, z below the twist) at the same time.  The recurrences are dependent
+//         chains: the operands of 8 steps are fetched from LDS together. ----
+__device__ void wg_twisted128(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f64* zn /*LDS 64 + 64 (partial norms)*/) {
     lds_f64* L = (lds_f64*)lds;
     lds_f64 *dg = L + EIG_TAIL, *e = dg + 128, *lam = dg + 256;
     lds_f64 *Dp = L, *Dm = L + 64 * EIG_N;                       // [row][lane]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (d_i, e_i) pairs in the reflector scalars' slot are not available: the bisection's pair array lives in L[256..512) = Dp rows
+    // 4..7, so the chains read dg / e directly in chunks
     double emax = 0.0;
     for (int t = 0; t < EIG_N - 1; ++t) emax = fmax(emax, e[t] * e[t]);
     const double pivmin = DBL_MIN * fmax(1.0, emax);
-    __syncthreads();                                             // e2 (aliasing Dp) is no longer read
-    // one wave, one lane per vector (r <= 64)
-    {
-        const int j0 = 0;
+    __syncthreads();                                             // the bisection's arrays (aliasing Dp) are no longer read
+    const bool act = lane < r;
+    const double lm = lam[act ? lane : 0];
+    if (wave == 0) {                                             // D+_0 = d_0 - lam ; D+_i = (d_i - lam) - e_{i-1}^2 / D+_{i-1}
+        double q = 1.0;
+        for (int i0 = 0; i0 < EIG_N; i0 += 8) {
+            double dd[8], ee[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { dd[t] = dg[i0 + t]; ee[t] = (i0 + t > 0) ? e[i0 + t - 1] : 0.0; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                q = fma(-(ee[t] * ee[t]), fast_rcp(q), dd[t] - lm);
+                if (fabs(q) < pivmin) q = -pivmin;
+                Dp[(i0 + t) * 64 + lane] = q;
+            }
+        }
+    } else if (wave == 1) {                                      // D-_{n-1} = d_{n-1} - lam ; D-_i = (d_i - lam) - e_i^2 / D-_{i+1}
+        double q = 1.0;
+        for (int i0 = EIG_N - 8; i0 >= 0; i0 -= 8) {
+            double dd[8], ee[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { dd[t] = dg[i0 + t]; ee[t] = (i0 + t < EIG_N - 1) ? e[i0 + t] : 0.0; }
+#pragma unroll
+            for (int t = 7; t >= 0; --t) {
+                q = fma(-(ee[t] * ee[t]), fast_rcp(q), dd[t] - lm);
+                if (fabs(q) < pivmin) q = -pivmin;
+                Dm[(i0 + t) * 64 + lane] = q;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {
+        // twist index: argmin |gamma_i|, gamma_i = D+_i + D-_i - (d_i - lam)   (both waves, redundantly: independent iterations)
+        double gbest = 1e300;
+        int kb = 0;
+        for (int i = 0; i < EIG_N; ++i) {
+            const double g = fabs(Dp[i * 64 + lane] + Dm[i * 64 + lane] - (dg[i] - lm));
+            if (g < gbest) { gbest = g; kb = i; }
+        }
+        // z_k = 1; wave 0: upwards with D+, wave 1: downwards with D-; the entries replace the pivots they consumed
+        double z = 1.0, nrm = 0.0;
         if (wave == 0) {
-            const int j = j0 + lane;
-            const bool act = j < r;
-            const double lm = lam[act ? j : 0];
-            double q = dg[0] - lm;
-            if (fabs(q) < pivmin) q = -pivmin;
-            Dp[lane] = q;
-            for (int i = 1; i < EIG_N; ++i) {
-                q = fma(-(e[i - 1] * e[i - 1]), fast_rcp(q), dg[i] - lm);
-                if (fabs(q) < pivmin) q = -pivmin;
-                Dp[i * 64 + lane] = q;
-            }
-            q = dg[EIG_N - 1] - lm;
-            if (fabs(q) < pivmin) q = -pivmin;
-            Dm[(EIG_N - 1) * 64 + lane] = q;
-            double gbest = fabs(Dp[(EIG_N - 1) * 64 + lane] + q - (dg[EIG_N - 1] - lm));
-            int kb = EIG_N - 1;
-            for (int i = EIG_N - 2; i >= 0; --i) {
-                q = fma(-(e[i] * e[i]), fast_rcp(q), dg[i] - lm);
-                if (fabs(q) < pivmin) q = -pivmin;
-                Dm[i * 64 + lane] = q;
-                const double g = fabs(Dp[i * 64 + lane] + q - (dg[i] - lm));
-                if (g < gbest) { gbest = g; kb = i; }
-            }
-            // z_k = 1; upwards with D+, downwards with D-; the entries replace the pivots they consumed
-            double z = 1.0, nrm = 1.0;
             for (int i = kb - 1; i >= 0; --i) {
                 z = -(e[i] * fast_rcp(Dp[i * 64 + lane])) * z;
                 Dp[i * 64 + lane] = z;
                 nrm = fma(z, z, nrm);
             }
-            z = 1.0;
+            if (act) { tw[lane] = kb; zn[lane] = nrm; }
+        } else {
             for (int i = kb; i < EIG_N - 1; ++i) {
                 z = -(e[i] * fast_rcp(Dm[(i + 1) * 64 + lane])) * z;
                 Dm[(i + 1) * 64 + lane] = z;
                 nrm = fma(z, z, nrm);
             }
-            if (act) { tw[j] = kb; zn[j] = 1.0 / sqrt(nrm); }
+            if (act) zn[64 + lane] = nrm;
         }
-        __syncthreads();
     }
+    __syncthreads();
+    if (tid < 64 && tid < r) zn[tid] = 1.0 / sqrt(1.0 + zn[tid] + zn[64 + tid]);
+    __syncthreads();
 }
 
 // ---- 4. back-transformation and the driver ----
@@ -224,53 +271,56 @@ __device__ __noinline__ int wg_eig128(const double* Gg, double* Vst, int r, int 
     EIG_MARK(4)
     wg_twisted128(r, lds, iwork, (lds_f64*)dwork);
     EIG_MARK(5)
-    // Z into registers: thread = (column lane, rows 8*wave .. 8*wave+7)
+    // Z into registers: waves 0..7; a row of 16 lanes owns TWO columns (8 per wave), lane rc of the row holds rows 8*rc .. 8*rc+7
+    // of both — the dot products v_k' z are reductions over the 16 lanes of a row (4 DPP adds each): no LDS reduction and no
+    // barrier in the loop.  The reflectors are staged in LDS once (the D+ / D- arrays are dead after the load of Z).
     lds_f64 *Dp = L, *Dm = L + 64 * EIG_N;
-    double z[8];
-    {
-        const int kb = (lane < r) ? iwork[lane] : 0;
-        const double zn = (lane < r) ? ((lds_f64*)dwork)[lane] : 0.0;
+    const int rc = lane & 15, col0 = 8 * (wave & 7) + 2 * (lane >> 4);
+    double z[2][8];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int col = col0 + cc;
+        const int kb = (col < r) ? iwork[col] : 0;
+        const double zn = (col < r) ? ((lds_f64*)dwork)[col] : 0.0;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const int row = 8 * wave + t;
-            const double v = (row < kb) ? Dp[row * 64 + lane] : ((row == kb) ? 1.0 : Dm[row * 64 + lane]);
-            z[t] = v * zn;
+            const int row = 8 * rc + t;
+            const double v = (row < kb) ? Dp[row * 64 + col] : ((row == kb) ? 1.0 : Dm[row * 64 + col]);
+            z[cc][t] = v * zn;
         }
     }
     __syncthreads();
-    lds_f64* P = L;                                               // [2][16][64] partial dot products
-    double vk[8], vn[8];
-    {
-        const double* vp = Vst + (EIG_N - 3) * 128 + 8 * wave;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) vn[t] = vp[t];
-    }
-    for (int k = EIG_N - 3; k >= 0; --k) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) vk[t] = vn[t];
-        if (k > 0) {                                              // prefetch the next reflector (global memory, L2 resident)
-            const double* vp = Vst + (k - 1) * 128 + 8 * wave;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) vn[t] = vp[t];
-        }
-        double sdot = 0.0;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) sdot = fma(vk[t], z[t], sdot);
-        P[(k & 1) * 1024 + wave * 64 + lane] = sdot;
-        __syncthreads();
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) tot += P[(k & 1) * 1024 + w * 64 + lane];
-        tot *= beta[k];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) z[t] = fma(-tot, vk[t], z[t]);
-    }
+    for (int e_ = tid; e_ < (EIG_N - 2) * 128; e_ += TTN_WG) L[e_] = Vst[e_];
     __syncthreads();
+    if (wave < 8) {
+        typedef double __attribute__((ext_vector_type(2))) d2;
+        typedef __attribute__((address_space(3))) d2 lds_d2;
+        for (int k = EIG_N - 3; k >= 0; --k) {
+            const lds_d2* vp = (const lds_d2*)(L + k * 128 + 8 * rc);
+            double vk[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const d2 w2 = vp[t]; vk[2 * t] = w2.x; vk[2 * t + 1] = w2.y; }
+            const double bk = beta[k];
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { s0 = fma(vk[t], z[0][t], s0); s1 = fma(vk[t], z[1][t], s1); }
+            const double t0 = row16_sum(s0) * bk, t1 = row16_sum(s1) * bk;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { z[0][t] = fma(-t0, vk[t], z[0][t]); z[1][t] = fma(-t1, vk[t], z[1][t]); }
+        }
+    }
+    __syncthreads();                                              // everyone has consumed D+ / D-: the image may be written
     EIG_MARK(6)
-    if (lane < r) {
-        const double sg = sig[lane];                              // written above by this workgroup, barriers in between
+    if (wave < 8) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) L[lane * 128 + 8 * wave + t] = z[t] * sg;
+        for (int cc = 0; cc < 2; ++cc) {
+            const int col = col0 + cc;
+            if (col < r) {
+                const double sg = sig[col];                       // written above by this workgroup, barriers in between
+#pragma unroll
+                for (int t = 0; t < 8; ++t) L[col * 128 + 8 * rc + t] = z[cc][t] * sg;
+            }
+        }
     }
     __syncthreads();
     return 0;
