@@ -93,25 +93,58 @@ __device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double
     __syncthreads();
 }
 
-// number of eigenvalues of the tridiagonal below x.  de = LDS array of pairs (d_i, e_{i-1}^2) (e_{-1} = 0): the recurrence is
-// a dependent chain, so the operands of 8 steps are fetched together (4 ds_read_b128 each for d and e^2 would be the naive
-// form; pairs make it one b128 per step) and the LDS latency is paid once per chunk
-__device__ inline int sturm_count(const lds_f64* de, double x, double pivmin) {
-    typedef double __attribute__((ext_vector_type(2))) d2;
-    typedef __attribute__((address_space(3))) d2 lds_d2;
-    const lds_d2* p2 = (const lds_d2*)de;
-    double q = 1.0;                                               // e_{-1}^2 = 0: the first step gives d_0 - x
+// Number of eigenvalues of the tridiagonal below x = number of sign changes in the sequence of leading principal minors
+//   p_0 = 1, p_1 = d_0 - x, p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1}
+// (product form of the Sturm sequence: no reciprocal in the dependent chain).  The matrix is held in REGISTERS, distributed over
+// the 16 lanes of every row of lanes (lane l holds d_{16g+l}, e^2_{16g+l-1} for g = 0..7), and each step takes its two
+// coefficients through the DPP row broadcast of the fp64 multiply-add — no LDS traffic at all in the 128-step loop (broadcast LDS
+// reads cost ~16 clk of the LDS pipe per wave and were the bound of this phase).  The pair (p_i, p_{i-1}) is rescaled by a power
+// of two when it leaves [2^-400, 2^400] (checked every 16 steps); an exact zero minor takes the sign opposite to its predecessor.
+// ereg holds -e^2 (the sign folded in).  Sign changes are counted from a shift register of sign bits (one v_alignbit per step);
+// `zero` reports whether some minor was exactly zero (the caller then repeats the evaluation with sturm_count_guarded).
+__device__ __forceinline__ int sturm_count(const double (&dreg)[8], const double (&ereg)[8], double x, bool& zero) {
+    double pc = 1.0, pp = 0.0;                                    // p_i, p_{i-1}
+    const double nx = -x, one = 1.0;
     int cnt = 0;
-    for (int i0 = 0; i0 < EIG_N; i0 += 8) {
-        d2 v[8];
+    bool z = false;
+    unsigned int prev = 0;                                        // sign bit of the last minor of the previous group (p_0 = 1 > 0)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = p2[i0 + t];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if (fabs(q) < pivmin) q = -pivmin;
-            q = fma(-v[t].y, fast_rcp(q), v[t].x - x);
-            cnt += (q < 0.0) ? 1 : 0;
+    for (int g = 0; g < 8; ++g) {
+        unsigned int bits = 0;
+#define EIG_ST(j) {                                                                                               \
+            double tt = 0.0, dmx = nx;                                                                            \
+            fmac_bcast<j>(tt, ereg[g], pp);                       /* -e_{i-1}^2 p_{i-1} */                         \
+            fmac_bcast<j>(dmx, dreg[g], one);                     /* d_i - x in one rounding */                    \
+            const double pn = fma(dmx, pc, tt);                                                                   \
+            z |= (pn == 0.0);                                                                                     \
+            bits = __builtin_amdgcn_alignbit(bits, (unsigned int)(__double_as_longlong(pn) >> 32), 31);           \
+            pp = pc; pc = pn; }
+        EIG_BCAST16(EIG_ST)
+#undef EIG_ST
+        // bits: bit 15 = sign of the first minor of the group ... bit 0 = the last; changes between neighbours, and against `prev`
+        const unsigned int seq = (prev << 16) | (bits & 0xffffu);
+        cnt += __popc((seq ^ (seq >> 1)) & 0xffffu);
+        prev = bits & 1u;
+        const double ap = fabs(pc);
+        if (ap < 0x1p-400 || ap > 0x1p400) {
+            const double sc = (ap < 1.0) ? 0x1p500 : 0x1p-500;
+            pc *= sc; pp *= sc;
         }
+    }
+    zero = z;
+    return cnt;
+}
+// the same count with the zero-minor rule applied step by step (slow path, taken only when `zero` was reported)
+__device__ __noinline__ int sturm_count_guarded(const lds_f64* de, double x) {
+    double pc = 1.0, pp = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < EIG_N; ++i) {
+        double pn = fma(de[2 * i] - x, pc, de[2 * i + 1] * pp);
+        if (pn == 0.0) pn = copysign(DBL_MIN, -pc);
+        cnt += (int)(((unsigned long long)(__double_as_longlong(pn) ^ __double_as_longlong(pc))) >> 63);
+        pp = pc; pc = pn;
+        const double ap = fabs(pc);
+        if (ap < 0x1p-400 || ap > 0x1p400) { const double sc = (ap < 1.0) ? 0x1p500 : 0x1p-500; pc *= sc; pp *= sc; }
     }
     return cnt;
 }
@@ -123,8 +156,10 @@ __device__ void wg_bisect128(int nev, double* lds) {
     lds_f64 *dg = L + EIG_TAIL, *e = dg + 128, *lam = dg + 256;
     lds_f64* e2 = L;                                             // phase-1 work area is free
     const int tid = threadIdx.x;
-    lds_f64* de = L + 256;                                        // pairs (d_i, e_{i-1}^2)
-    for (int t = tid; t < EIG_N; t += TTN_WG) { e2[t] = (t < EIG_N - 1) ? e[t] * e[t] : 0.0; de[2 * t] = dg[t]; de[2 * t + 1] = (t > 0) ? e[t - 1] * e[t - 1] : 0.0; }
+    lds_f64* de = L + 256;                                        // pairs (d_i, -e_{i-1}^2); the DPP source registers below must come
+                                                                  // straight from ds_read: a VALU write right before a DPP read of the
+                                                                  // same register is a hazard the compiler cannot see through inline asm
+    for (int t = tid; t < EIG_N; t += TTN_WG) { e2[t] = (t < EIG_N - 1) ? e[t] * e[t] : 0.0; de[2 * t] = dg[t]; de[2 * t + 1] = (t > 0) ? -(e[t - 1] * e[t - 1]) : 0.0; }
     __syncthreads();
     // Gershgorin interval and the pivot floor: wave 0, results through LDS (e2[128..130])
     if (tid < 64) {
@@ -143,6 +178,10 @@ __device__ void wg_bisect128(int nev, double* lds) {
     const double span = fmax(fabs(glo), fabs(ghi));
     glo -= 2.0 * DBL_EPSILON * span * EIG_N; ghi += 2.0 * DBL_EPSILON * span * EIG_N;
     const double pivmin = DBL_MIN * fmax(1.0, emax);
+    double dreg[8], ereg[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { dreg[g] = de[2 * (16 * g + (tid & 15))]; ereg[g] = de[2 * (16 * g + (tid & 15)) + 1]; }
+    asm volatile("s_nop 1");
     for (int g0 = 0; g0 < nev; g0 += TTN_WG / TL) {
         const int gi = g0 + tid / TL, sub = tid % TL;
         const bool act = gi < nev;
@@ -156,7 +195,9 @@ __device__ void wg_bisect128(int nev, double* lds) {
             const double x = lo + wdt * ((double)(sub + 1) / (double)(TL + 1));
             // waves whose groups are all beyond nev skip the count (wave-uniform branch): they would only compete for issue slots
             const bool wave_act = g0 + (tid & ~63) / TL < nev;
-            const int cnt = wave_act ? sturm_count(de, x, pivmin) : 0;
+            bool zero = false;
+            int cnt = wave_act ? sturm_count(dreg, ereg, x, zero) : 0;
+            if (zero) cnt = sturm_count_guarded(de, x);
             // nf = number of section points with count <= jasc (monotone in sub): the eigenvalue lies right of point nf-1
             int nf = (cnt <= jasc) ? 1 : 0;
 #pragma unroll
