@@ -1299,15 +1299,15 @@ int ttn_selftest_eig128(const double* G, int64_t r, int64_t nev, double* sig, do
     HIPCHK(hipMalloc((void**)&dV, sizeof(double) * 128 * 128));
     HIPCHK(hipMalloc((void**)&dS, sizeof(double) * 128));
     HIPCHK(hipMalloc((void**)&dX, sizeof(double) * 128 * 64));
-    HIPCHK(hipMalloc((void**)&dC, sizeof(long long) * 8));
+    HIPCHK(hipMalloc((void**)&dC, sizeof(long long) * 16));
     HIPCHK(hipMemcpyAsync(dG, G, sizeof(double) * 128 * 128, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(dX, 0, sizeof(double) * 128 * 64, g_stream));
     hipLaunchKernelGGL(k_selftest_eig128, dim3(1), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, dG, dV, (int)r, (int)nev, dS, dX, dC);
     HIPCHK(hipGetLastError());
-    long long hc[8] = {0};
+    long long hc[16] = {0};
     HIPCHK(hipMemcpyAsync(sig, dS, sizeof(double) * nev, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipMemcpyAsync(X, dX, sizeof(double) * 128 * r, hipMemcpyDeviceToHost, g_stream));
-    HIPCHK(hipMemcpyAsync(hc, dC, sizeof(long long) * 8, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(hc, dC, sizeof(long long) * 16, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     if (ticks_rc) { ticks_rc[0] = hc[0]; ticks_rc[1] = hc[1]; for (int t = 2; t < 6; ++t) ticks_rc[t] = hc[t + 1] - hc[t]; }   // tridiag, bisect, twisted, back-transform
     hipFree(dG); hipFree(dV); hipFree(dS); hipFree(dX); hipFree(dC);

@@ -27,38 +27,67 @@ __device__ __forceinline__ void fmac_bcast(double& a, double w, double s_) {
 #define EIG_TAIL (EIG_N * EIG_N)
 
 // ---- 1. tridiagonalisation: dg[0..127], e[0..126] (e[k] couples k, k+1), reflectors v_k (rows of Vst, zeros up to k) and beta_k ----
+// Per column k:  v_k, beta_k (reflector of column k below the diagonal);  p = beta A v;  w = p - (beta/2)(p'v) v;  A -= v w' + w v'.
+// The reflector and w are "scalar-ish" code run by wave 0 alone.  Look-ahead: the owners of row k+1 publish it BEFORE the update
+// of step k, so wave 0 can form column k+1 of the updated matrix (x - v w_{k+1} - w v_{k+1}) and the NEXT reflector while the
+// other waves are still applying update k — 3 barriers per column and the reflector off the critical path.
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding GLOBAL stores (the
+// reflector rows written to Vst for the back-transformation), ~1 k clk per column of the tridiagonalisation for nothing.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// lane `idx` (wave-uniform) of a double
+__device__ __forceinline__ double readlane_f64(double v, int idx) {
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], idx);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], idx);
+    return r.d;
+}
+__device__ __forceinline__ void tridiag_reflector(int k, double x0, double x1, double xk1, int lane, lds_f64* vbuf, double* Vst,
+                                                  lds_f64* dg, lds_f64* e, lds_f64* beta, double dgk) {
+    // lanes hold entries lane, lane + 64 of column k (zero at and above the diagonal position k)
+    const double s2 = wave64_sum_fast(fma(x0, x0, x1 * x1));
+    // sqrt and reciprocal from the hardware seeds + Newton steps (full fp64 accuracy; this chain is on the critical path)
+    const double alpha = (s2 > 0.0) ? -copysign(s2 * fast_rsqrt2(s2), xk1) : 0.0;
+    const double den = s2 - alpha * xk1;                           // = v'v / 2
+    double bta = 0.0;
+    if (den > 0.0) { bta = fast_rcp(den); bta = fma(fma(-den, bta, 1.0), bta, bta); }
+    const double v0 = x0 - ((lane == k + 1) ? alpha : 0.0), v1 = x1 - ((lane + 64 == k + 1) ? alpha : 0.0);
+    vbuf[lane] = v0; vbuf[lane + 64] = v1;
+    // global_store, not flat_store: a flat store also counts on lgkmcnt, and the LDS barrier right after would wait for it (~800 clk)
+    typedef __attribute__((address_space(1))) double gdouble;
+    gdouble* vg = (gdouble*)(unsigned long long)(Vst + k * 128);
+    vg[lane] = v0; vg[lane + 64] = v1;
+    if (lane == 0) { dg[k] = dgk; e[k] = alpha; beta[k] = bta; }
+}
+
 __device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double* lds) {
     Gg = unip(Gg); Vst = unip(Vst); lds = unip(lds);
     lds_f64* L = (lds_f64*)lds;
-    lds_f64 *vL = L, *wL = L + 128, *xcol = L + 256, *part = L + 384;
+    lds_f64 *vbuf0 = L, *vbuf1 = L + 128, *wL = L + 256, *xnext = L + 384, *part = L + 512;      // part: 8 x 128
     lds_f64 *dg = L + EIG_TAIL, *e = dg + 128, *beta = dg + 384;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tid & 127, c = tid >> 7;
     double a[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) a[j] = Gg[i + 128 * (16 * c + j)];
-    for (int k = 0; k < EIG_N - 2; ++k) {
-        // row k of the current matrix (= column k by symmetry) from its 8 owners
-        if (i == k) {
+    // prologue: rows 0 and 1 of the matrix; reflector 0
+    if (i == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xcol[16 * c + j] = a[j];
-        }
-        __syncthreads();
-        // the reflector: wave 0 only (lane handles entries lane, lane + 64) — the other waves wait at the barrier instead of
-        // spending issue slots of the shared SIMDs on redundant copies of this scalar-ish code
-        if (wave == 0) {
-            const double x0 = (lane > k) ? xcol[lane] : 0.0, x1 = (lane + 64 > k) ? xcol[lane + 64] : 0.0;
-            const double s2 = wave64_sum_fast(fma(x0, x0, x1 * x1));
-            const double xk1 = xcol[k + 1];
-            const double alpha = (s2 > 0.0) ? -copysign(sqrt(s2), xk1) : 0.0;
-            const double den = s2 - alpha * xk1;                   // = v'v / 2
-            const double bta = (den > 0.0) ? 1.0 / den : 0.0;
-            const double v0 = x0 - ((lane == k + 1) ? alpha : 0.0), v1 = x1 - ((lane + 64 == k + 1) ? alpha : 0.0);
-            vL[lane] = v0; vL[lane + 64] = v1;
-            Vst[k * 128 + lane] = v0; Vst[k * 128 + lane + 64] = v1;
-            if (lane == 0) { dg[k] = xcol[k]; e[k] = alpha; beta[k] = bta; }
-        }
-        __syncthreads();
+        for (int j = 0; j < 16; ++j) wL[16 * c + j] = a[j];      // row 0 (wL is free here)
+    }
+    if (i == 1) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xnext[16 * c + j] = a[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const double x0 = (lane > 0) ? wL[lane] : 0.0, x1 = wL[lane + 64];
+        tridiag_reflector(0, x0, x1, wL[1], lane, vbuf0, Vst, dg, e, beta, wL[0]);
+    }
+    for (int k = 0; k < EIG_N - 2; ++k) {
+        lds_f64* vL = (k & 1) ? vbuf1 : vbuf0;
+        lds_f64* vN = (k & 1) ? vbuf0 : vbuf1;
+        lds_barrier();                                             // v_k, row k+1 (xnext) are visible
         // p = A v (partial over the thread's 16 columns): lane l of a row of 16 lanes holds v[16c + l], the DPP multiply-add
         // broadcasts it — 2 LDS reads per thread and step instead of 48
         const double vreg = vL[16 * c + (lane & 15)];
@@ -68,17 +97,20 @@ __device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double
         EIG_BCAST16(EIG_MV)
 #undef EIG_MV
         part[c * 128 + i] = pp;
-        __syncthreads();
+        lds_barrier();   
+        double v0 = 0.0, v1 = 0.0, w0 = 0.0, w1 = 0.0;
         if (wave == 0) {
-            const double bta = beta[k], v0 = vL[lane], v1 = vL[lane + 64];
+            const double bta = beta[k];
+            v0 = vL[lane]; v1 = vL[lane + 64];
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) { p0 += part[cc * 128 + lane]; p1 += part[cc * 128 + lane + 64]; }
             p0 *= bta; p1 *= bta;
             const double Kc = 0.5 * bta * wave64_sum_fast(fma(p0, v0, p1 * v1));
-            wL[lane] = fma(-Kc, v0, p0); wL[lane + 64] = fma(-Kc, v1, p1);
+            w0 = fma(-Kc, v0, p0); w1 = fma(-Kc, v1, p1);
+            wL[lane] = w0; wL[lane + 64] = w1;
         }
-        __syncthreads();
+        lds_barrier();   
         // A -= v w' + w v'
         const double wreg = wL[16 * c + (lane & 15)];
         const double nvi = -vL[i], nwi = -wL[i];
@@ -86,8 +118,29 @@ __device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double
 #define EIG_UP(j) fmac_bcast<j>(a[j], wreg, nvi); fmac_bcast<j>(a[j], vreg, nwi);
         EIG_BCAST16(EIG_UP)
 #undef EIG_UP
+        // row k+2 of the UPDATED matrix for the look-ahead of the next step (xnext is read by wave 0 below: the owners of row
+        // k+2 write a second buffer — the two alternate)
+        lds_f64* xn_r = (k & 1) ? xnext + 1152 : xnext;          // read this step (row k+1 before update k)
+        lds_f64* xn_w = (k & 1) ? xnext : xnext + 1152;          // written this step (row k+2 after update k)
+        if (i == k + 2) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xn_w[16 * c + j] = a[j];
+        }
+        if (wave == 0 && k + 1 < EIG_N - 2) {
+            // column k+1 of the updated matrix: x - v w_{k+1} - w v_{k+1}, then reflector k+1 (entries <= k+1 are not part of it)
+            const double wk1 = wL[k + 1], vk1 = vL[k + 1];
+            const double c0 = fma(-v0, wk1, fma(-w0, vk1, xn_r[lane]));
+            const double c1 = fma(-v1, wk1, fma(-w1, vk1, xn_r[lane + 64]));
+            // broadcast entries k+1 (the new diagonal) and k+2 through LDS-free lane reads
+            const int kk = k + 1;
+            const double dgk = (kk < 64) ? readlane_f64(c0, kk) : readlane_f64(c1, kk - 64);
+            const double xk1 = (kk + 1 < 64) ? readlane_f64(c0, kk + 1) : readlane_f64(c1, kk + 1 - 64);
+            const double x0 = (lane > kk) ? c0 : 0.0, x1 = (lane + 64 > kk) ? c1 : 0.0;
+            tridiag_reflector(kk, x0, x1, xk1, lane, vN, Vst, dg, e, beta, dgk);
+        }
     }
     // the last 2 x 2 block
+    __syncthreads();
     if (i == EIG_N - 2 && c == 7) { dg[EIG_N - 2] = a[14]; e[EIG_N - 2] = a[15]; }
     if (i == EIG_N - 1 && c == 7) { dg[EIG_N - 1] = a[15]; }
     __syncthreads();
