@@ -186,11 +186,11 @@ int ttn_event_elapsed(int64_t slot_a, int64_t slot_b, float* ms);
 int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const double* B, double* C, double alpha, double beta,
                       int ta, int tb);
 
-/* self-test of the 128 x 128 symmetric eigensolver used by the Gram route (csrc/ttn_eig_kernels.h): G host, column-major,
- * symmetric positive definite; sig[nev] = sqrt of the nev largest eigenvalues (descending), X[128*r] = sig_j * u_j (r <= 64);
+/* self-test of the symmetric eigensolver used by the Gram routes (csrc/ttn_eig_kernels.h): G host, n x n (n = 64 or 128),
+ * column-major, symmetric positive definite; sig[nev] = sqrt of the nev largest eigenvalues (descending), X[128*r] = sig_j * u_j (r <= 64);
  * ticks_rc[0] = device clock ticks (s_memtime), [1] = return code of the device routine, [2..5] = ticks of the four phases
  * (tridiagonalisation, bisection, twisted factorisations, back-transformation); ticks_rc has 6 entries. */
-int ttn_selftest_eig128(const double* G, int64_t r, int64_t nev, double* sig, double* X, int64_t* ticks_rc);
+int ttn_selftest_eig128(const double* G, int64_t n, int64_t r, int64_t nev, double* sig, double* X, int64_t* ticks_rc);
 /* micro-benchmark hook: the same workgroup GEMM on ONE compute unit, `reps` times back to back on device-resident zeros;
  * cycles_out receives the shader-clock cycles (s_memtime) of the whole loop.  Used to price the dense phases against the
  * per-CU fp64 MFMA peak (128 flop/clk/CU). */

@@ -1289,10 +1289,10 @@ int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const do
 
 // self-test of the 128 x 128 symmetric eigensolver of the Gram route: G (host, column-major) -> sig[nev] = sqrt(eigenvalues)
 // descending, X[128 * r] = sqrt(lam_j) u_j, cycles (s_memtime ticks) and the return code of the device routine
-int ttn_selftest_eig128(const double* G, int64_t r, int64_t nev, double* sig, double* X, int64_t* ticks_rc) {
+int ttn_selftest_eig128(const double* G, int64_t n, int64_t r, int64_t nev, double* sig, double* X, int64_t* ticks_rc) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     NEED_INIT();
-    if (!G || !sig || !X || r < 1 || r > 64 || nev < r || nev > 128) return fail(TTN_ERR_ARG, "bad argument");
+    if (!G || !sig || !X || (n != 64 && n != 128) || r < 1 || r > 64 || nev < r || nev > n) return fail(TTN_ERR_ARG, "bad argument");
     double *dG = nullptr, *dV = nullptr, *dS = nullptr, *dX = nullptr;
     long long* dC = nullptr;
     HIPCHK(hipMalloc((void**)&dG, sizeof(double) * 128 * 128));
@@ -1300,9 +1300,9 @@ int ttn_selftest_eig128(const double* G, int64_t r, int64_t nev, double* sig, do
     HIPCHK(hipMalloc((void**)&dS, sizeof(double) * 128));
     HIPCHK(hipMalloc((void**)&dX, sizeof(double) * 128 * 64));
     HIPCHK(hipMalloc((void**)&dC, sizeof(long long) * 16));
-    HIPCHK(hipMemcpyAsync(dG, G, sizeof(double) * 128 * 128, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(dG, G, sizeof(double) * n * n, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(dX, 0, sizeof(double) * 128 * 64, g_stream));
-    hipLaunchKernelGGL(k_selftest_eig128, dim3(1), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, dG, dV, (int)r, (int)nev, dS, dX, dC);
+    hipLaunchKernelGGL(k_selftest_eig128, dim3(1), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, dG, dV, (int)n, (int)r, (int)nev, dS, dX, dC);
     HIPCHK(hipGetLastError());
     long long hc[16] = {0};
     HIPCHK(hipMemcpyAsync(sig, dS, sizeof(double) * nev, hipMemcpyDeviceToHost, g_stream));

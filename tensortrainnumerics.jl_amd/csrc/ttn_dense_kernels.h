@@ -1661,6 +1661,7 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
 // are U and S*Vt instead of U sqrt(S), sqrt(S) Vt.  Only route H is used (the swapped matrices are rank deficient by design).
 // symmetric eigensolver of the Gram route (ttn_eig_kernels.h, included after this header by the translation unit)
 __device__ int wg_eig128(const double* Gg, double* Vst, int r, int nev, double* sig, double* lds, int* iwork, double* dwork, long long* prof);
+__device__ int wg_eig64(const double* Gg, int ldg, double* Vst, int r, int nev, double* sig, double* lds, int* iwork, double* dwork);
 
 struct BondIO {
     double *ck, *ck1;            // the two cores (slots)
@@ -1774,11 +1775,22 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             PROF_MARK(9)
             // core C = L_A^T L_B  (rm x rm)
             wg_gemm(rm, rm, rm, tview(Gav), Gbv, Ccv, 1.0, 0.0, lds);
-            for (int e = tid; e < rm * 128; e += TTN_WG) { const int c = e >> 7, r_ = e & 127; S.ldsX[e] = (r_ < rm) ? S.Cc[c * 128 + r_] : 0.0; }
-            __syncthreads();
-            const int nsw = uni32(wg_svd_cols(P, S, rm, S.ldsX, 128, true));
-            nsw_total += (nsw < 0 ? -nsw : nsw);
-            ok = (nsw > 0) && (S.sigs[rm - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[rm - 1] * S.sigs[rm - 1] > S.scal[0]);
+            int nsw = 1;
+            if (rm == 64 && !(P.fast & 4)) {
+                // the 64 x 64 core through the symmetric eigensolver: C C' = U S^2 U' gives the same image x_j = sigma_j u_j the
+                // Jacobi on the columns of C leaves (ttn_eig_kernels.h; the a-posteriori check below covers the squared condition)
+                wg_gemm(64, 64, 64, Ccv, tview(Ccv), mkview(S.T3, plain(1), plain(128)), 1.0, 0.0, lds);
+                ok = wg_eig64(S.T3, 128, S.T2, 64, 64, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64) == 0;
+                for (int j = tid; j < 64; j += TTN_WG) S.perm[j] = j;
+                if (tid == 0) S.scal[0] = P.jneg_mult * P.jneg_mult * 64.0 * DBL_EPSILON * DBL_EPSILON * S.sigs[0] * S.sigs[0];
+                __syncthreads();
+            } else {
+                for (int e = tid; e < rm * 128; e += TTN_WG) { const int c = e >> 7, r_ = e & 127; S.ldsX[e] = (r_ < rm) ? S.Cc[c * 128 + r_] : 0.0; }
+                __syncthreads();
+                nsw = uni32(wg_svd_cols(P, S, rm, S.ldsX, 128, true));
+                nsw_total += (nsw < 0 ? -nsw : nsw);
+            }
+            ok = ok && (nsw > 0) && (S.sigs[rm - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[rm - 1] * S.sigs[rm - 1] > S.scal[0]);
             PROF_MARK(10)
         }
         if (ok) {

@@ -60,89 +60,97 @@ __device__ __forceinline__ void tridiag_reflector(int k, double x0, double x1, d
     if (lane == 0) { dg[k] = dgk; e[k] = alpha; beta[k] = bta; }
 }
 
-__device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double* lds) {
-    Gg = unip(Gg); Vst = unip(Vst); lds = unip(lds);
+template <int N>
+__device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, double* lds) {
+    Gg = unip(Gg); Vst = unip(Vst); lds = unip(lds); ldg = uni32(ldg);
+    constexpr bool TWO = (N == 128);                              // wave 0 holds one (N = 64) or two entries of a vector per lane
+    constexpr int NC = N / 16;                                    // 16-column chunks; thread = (row i, chunk c), tid < N * NC
     lds_f64* L = (lds_f64*)lds;
     lds_f64 *vbuf0 = L, *vbuf1 = L + 128, *wL = L + 256, *xnext = L + 384, *part = L + 512;      // part: 8 x 128
     lds_f64 *dg = L + EIG_TAIL, *e = dg + 128, *beta = dg + 384;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = tid & 127, c = tid >> 7;
+    const int i = tid & (N - 1), c = tid / N;
+    const bool actv = tid < N * NC;
     double a[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = Gg[i + 128 * (16 * c + j)];
+    for (int j = 0; j < 16; ++j) a[j] = actv ? Gg[i + (long long)ldg * (16 * c + j)] : 0.0;
     // prologue: rows 0 and 1 of the matrix; reflector 0
-    if (i == 0) {
+    if (actv && i == 0) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) wL[16 * c + j] = a[j];      // row 0 (wL is free here)
     }
-    if (i == 1) {
+    if (actv && i == 1) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) xnext[16 * c + j] = a[j];
     }
     __syncthreads();
     if (wave == 0) {
-        const double x0 = (lane > 0) ? wL[lane] : 0.0, x1 = wL[lane + 64];
+        const double x0 = (lane > 0) ? wL[lane] : 0.0, x1 = TWO ? wL[lane + 64] : 0.0;
         tridiag_reflector(0, x0, x1, wL[1], lane, vbuf0, Vst, dg, e, beta, wL[0]);
     }
-    for (int k = 0; k < EIG_N - 2; ++k) {
+    for (int k = 0; k < N - 2; ++k) {
         lds_f64* vL = (k & 1) ? vbuf1 : vbuf0;
         lds_f64* vN = (k & 1) ? vbuf0 : vbuf1;
         lds_barrier();                                             // v_k, row k+1 (xnext) are visible
         // p = A v (partial over the thread's 16 columns): lane l of a row of 16 lanes holds v[16c + l], the DPP multiply-add
         // broadcasts it — 2 LDS reads per thread and step instead of 48
-        const double vreg = vL[16 * c + (lane & 15)];
-        double pp = 0.0;
-        asm volatile("s_nop 1");
+        double vreg = 0.0;
+        if (actv) {
+            vreg = vL[16 * c + (lane & 15)];
+            double pp = 0.0;
+            asm volatile("s_nop 1");
 #define EIG_MV(j) fmac_bcast<j>(pp, vreg, a[j]);
-        EIG_BCAST16(EIG_MV)
+            EIG_BCAST16(EIG_MV)
 #undef EIG_MV
-        part[c * 128 + i] = pp;
-        lds_barrier();   
+            part[c * 128 + i] = pp;
+        }
+        lds_barrier();
         double v0 = 0.0, v1 = 0.0, w0 = 0.0, w1 = 0.0;
         if (wave == 0) {
             const double bta = beta[k];
-            v0 = vL[lane]; v1 = vL[lane + 64];
+            v0 = vL[lane]; v1 = TWO ? vL[lane + 64] : 0.0;
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) { p0 += part[cc * 128 + lane]; p1 += part[cc * 128 + lane + 64]; }
+            for (int cc = 0; cc < NC; ++cc) { p0 += part[cc * 128 + lane]; if (TWO) p1 += part[cc * 128 + lane + 64]; }
             p0 *= bta; p1 *= bta;
             const double Kc = 0.5 * bta * wave64_sum_fast(fma(p0, v0, p1 * v1));
             w0 = fma(-Kc, v0, p0); w1 = fma(-Kc, v1, p1);
-            wL[lane] = w0; wL[lane + 64] = w1;
+            wL[lane] = w0; if (TWO) wL[lane + 64] = w1;
         }
-        lds_barrier();   
-        // A -= v w' + w v'
-        const double wreg = wL[16 * c + (lane & 15)];
-        const double nvi = -vL[i], nwi = -wL[i];
-        asm volatile("s_nop 1");
-#define EIG_UP(j) fmac_bcast<j>(a[j], wreg, nvi); fmac_bcast<j>(a[j], vreg, nwi);
-        EIG_BCAST16(EIG_UP)
-#undef EIG_UP
-        // row k+2 of the UPDATED matrix for the look-ahead of the next step (xnext is read by wave 0 below: the owners of row
-        // k+2 write a second buffer — the two alternate)
+        lds_barrier();
+        // row k+2 of the UPDATED matrix goes to the look-ahead buffer the next step reads (two buffers alternate)
         lds_f64* xn_r = (k & 1) ? xnext + 1152 : xnext;          // read this step (row k+1 before update k)
         lds_f64* xn_w = (k & 1) ? xnext : xnext + 1152;          // written this step (row k+2 after update k)
-        if (i == k + 2) {
+        if (actv) {
+            // A -= v w' + w v'
+            const double wreg = wL[16 * c + (lane & 15)];
+            const double nvi = -vL[i], nwi = -wL[i];
+            asm volatile("s_nop 1");
+#define EIG_UP(j) fmac_bcast<j>(a[j], wreg, nvi); fmac_bcast<j>(a[j], vreg, nwi);
+            EIG_BCAST16(EIG_UP)
+#undef EIG_UP
+            if (i == k + 2) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xn_w[16 * c + j] = a[j];
+                for (int j = 0; j < 16; ++j) xn_w[16 * c + j] = a[j];
+            }
         }
-        if (wave == 0 && k + 1 < EIG_N - 2) {
+        if (wave == 0 && k + 1 < N - 2) {
             // column k+1 of the updated matrix: x - v w_{k+1} - w v_{k+1}, then reflector k+1 (entries <= k+1 are not part of it)
             const double wk1 = wL[k + 1], vk1 = vL[k + 1];
             const double c0 = fma(-v0, wk1, fma(-w0, vk1, xn_r[lane]));
-            const double c1 = fma(-v1, wk1, fma(-w1, vk1, xn_r[lane + 64]));
-            // broadcast entries k+1 (the new diagonal) and k+2 through LDS-free lane reads
+            const double c1 = TWO ? fma(-v1, wk1, fma(-w1, vk1, xn_r[lane + 64])) : 0.0;
+            // entries k+1 (the new diagonal) and k+2 by lane reads
             const int kk = k + 1;
             const double dgk = (kk < 64) ? readlane_f64(c0, kk) : readlane_f64(c1, kk - 64);
             const double xk1 = (kk + 1 < 64) ? readlane_f64(c0, kk + 1) : readlane_f64(c1, kk + 1 - 64);
-            const double x0 = (lane > kk) ? c0 : 0.0, x1 = (lane + 64 > kk) ? c1 : 0.0;
+            const double x0 = (lane > kk) ? c0 : 0.0, x1 = (TWO && lane + 64 > kk) ? c1 : 0.0;
             tridiag_reflector(kk, x0, x1, xk1, lane, vN, Vst, dg, e, beta, dgk);
         }
     }
     // the last 2 x 2 block
     __syncthreads();
-    if (i == EIG_N - 2 && c == 7) { dg[EIG_N - 2] = a[14]; e[EIG_N - 2] = a[15]; }
-    if (i == EIG_N - 1 && c == 7) { dg[EIG_N - 1] = a[15]; }
+    if (actv && i == N - 2 && c == NC - 1) { dg[N - 2] = a[14]; e[N - 2] = a[15]; }
+    if (actv && i == N - 1 && c == NC - 1) { dg[N - 1] = a[15]; }
     __syncthreads();
 }
 
@@ -155,14 +163,15 @@ __device__ __noinline__ void wg_tridiag128(const double* Gg, double* Vst, double
 // of two when it leaves [2^-400, 2^400] (checked every 16 steps); an exact zero minor takes the sign opposite to its predecessor.
 // ereg holds -e^2 (the sign folded in).  Sign changes are counted from a shift register of sign bits (one v_alignbit per step);
 // `zero` reports whether some minor was exactly zero (the caller then repeats the evaluation with sturm_count_guarded).
-__device__ __forceinline__ int sturm_count(const double (&dreg)[8], const double (&ereg)[8], double x, bool& zero) {
+template <int N>
+__device__ __forceinline__ int sturm_count(const double (&dreg)[N / 16], const double (&ereg)[N / 16], double x, bool& zero) {
     double pc = 1.0, pp = 0.0;                                    // p_i, p_{i-1}
     const double nx = -x, one = 1.0;
     int cnt = 0;
     bool z = false;
     unsigned int prev = 0;                                        // sign bit of the last minor of the previous group (p_0 = 1 > 0)
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < N / 16; ++g) {
         unsigned int bits = 0;
 #define EIG_ST(j) {                                                                                               \
             double tt = 0.0, dmx = nx;                                                                            \
@@ -188,10 +197,10 @@ __device__ __forceinline__ int sturm_count(const double (&dreg)[8], const double
     return cnt;
 }
 // the same count with the zero-minor rule applied step by step (slow path, taken only when `zero` was reported)
-__device__ __noinline__ int sturm_count_guarded(const lds_f64* de, double x) {
+__device__ __noinline__ int sturm_count_guarded(const lds_f64* de, double x, int n) {
     double pc = 1.0, pp = 0.0;
     int cnt = 0;
-    for (int i = 0; i < EIG_N; ++i) {
+    for (int i = 0; i < n; ++i) {
         double pn = fma(de[2 * i] - x, pc, de[2 * i + 1] * pp);
         if (pn == 0.0) pn = copysign(DBL_MIN, -pc);
         cnt += (int)(((unsigned long long)(__double_as_longlong(pn) ^ __double_as_longlong(pc))) >> 63);
@@ -203,8 +212,8 @@ __device__ __noinline__ int sturm_count_guarded(const lds_f64* de, double x) {
 }
 
 // ---- 2. eigenvalues lam[0..nev-1] in DESCENDING order (the nev largest), multisection with TL lanes per eigenvalue ----
-template <int TL>
-__device__ void wg_bisect128(int nev, double* lds) {
+template <int N, int TL>
+__device__ void wg_bisect(int nev, double* lds) {
     lds_f64* L = (lds_f64*)lds;
     lds_f64 *dg = L + EIG_TAIL, *e = dg + 128, *lam = dg + 256;
     lds_f64* e2 = L;                                             // phase-1 work area is free
@@ -212,13 +221,13 @@ __device__ void wg_bisect128(int nev, double* lds) {
     lds_f64* de = L + 256;                                        // pairs (d_i, -e_{i-1}^2); the DPP source registers below must come
                                                                   // straight from ds_read: a VALU write right before a DPP read of the
                                                                   // same register is a hazard the compiler cannot see through inline asm
-    for (int t = tid; t < EIG_N; t += TTN_WG) { e2[t] = (t < EIG_N - 1) ? e[t] * e[t] : 0.0; de[2 * t] = dg[t]; de[2 * t + 1] = (t > 0) ? -(e[t - 1] * e[t - 1]) : 0.0; }
+    for (int t = tid; t < N; t += TTN_WG) { e2[t] = (t < N - 1) ? e[t] * e[t] : 0.0; de[2 * t] = dg[t]; de[2 * t + 1] = (t > 0) ? -(e[t - 1] * e[t - 1]) : 0.0; }
     __syncthreads();
     // Gershgorin interval and the pivot floor: wave 0, results through LDS (e2[128..130])
     if (tid < 64) {
         double glo_ = 1e300, ghi_ = -1e300, emax_ = 0.0;
-        for (int t = tid; t < EIG_N; t += 64) {
-            const double rad = ((t > 0) ? fabs(e[t - 1]) : 0.0) + ((t < EIG_N - 1) ? fabs(e[t]) : 0.0);
+        for (int t = tid; t < N; t += 64) {
+            const double rad = ((t > 0) ? fabs(e[t - 1]) : 0.0) + ((t < N - 1) ? fabs(e[t]) : 0.0);
             glo_ = fmin(glo_, dg[t] - rad); ghi_ = fmax(ghi_, dg[t] + rad);
             emax_ = fmax(emax_, e2[t]);
         }
@@ -229,16 +238,16 @@ __device__ void wg_bisect128(int nev, double* lds) {
     double glo = e2[128], ghi = e2[129];
     const double emax = e2[130];
     const double span = fmax(fabs(glo), fabs(ghi));
-    glo -= 2.0 * DBL_EPSILON * span * EIG_N; ghi += 2.0 * DBL_EPSILON * span * EIG_N;
+    glo -= 2.0 * DBL_EPSILON * span * N; ghi += 2.0 * DBL_EPSILON * span * N;
     const double pivmin = DBL_MIN * fmax(1.0, emax);
-    double dreg[8], ereg[8];
+    double dreg[N / 16], ereg[N / 16];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) { dreg[g] = de[2 * (16 * g + (tid & 15))]; ereg[g] = de[2 * (16 * g + (tid & 15)) + 1]; }
+    for (int g = 0; g < N / 16; ++g) { dreg[g] = de[2 * (16 * g + (tid & 15))]; ereg[g] = de[2 * (16 * g + (tid & 15)) + 1]; }
     asm volatile("s_nop 1");
     for (int g0 = 0; g0 < nev; g0 += TTN_WG / TL) {
         const int gi = g0 + tid / TL, sub = tid % TL;
         const bool act = gi < nev;
-        const int jasc = EIG_N - 1 - (act ? gi : 0);            // ascending index of this group's eigenvalue
+        const int jasc = N - 1 - (act ? gi : 0);            // ascending index of this group's eigenvalue
         double lo = glo, hi = ghi;
         // rounds: (TL + 1)-section; stop when the interval is at rounding level
         for (int round = 0; round < 64; ++round) {
@@ -249,8 +258,8 @@ __device__ void wg_bisect128(int nev, double* lds) {
             // waves whose groups are all beyond nev skip the count (wave-uniform branch): they would only compete for issue slots
             const bool wave_act = g0 + (tid & ~63) / TL < nev;
             bool zero = false;
-            int cnt = wave_act ? sturm_count(dreg, ereg, x, zero) : 0;
-            if (zero) cnt = sturm_count_guarded(de, x);
+            int cnt = wave_act ? sturm_count<N>(dreg, ereg, x, zero) : 0;
+            if (zero) cnt = sturm_count_guarded(de, x, N);
             // nf = number of section points with count <= jasc (monotone in sub): the eigenvalue lies right of point nf-1
             int nf = (cnt <= jasc) ? 1 : 0;
 #pragma unroll
@@ -270,22 +279,23 @@ __device__ void wg_bisect128(int nev, double* lds) {
 //         twist index and 1/||z|| per vector in tw[], zn[].  One lane per vector; wave 0 runs the top-down recurrences (D+, then
 //         z above the twist), wave 1 the bottom-up ones (D-, z below the twist) at the same time.  The recurrences are dependent
 //         chains: the operands of 8 steps are fetched from LDS together. ----
-__device__ void wg_twisted128(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f64* zn /*LDS 64 + 64 (partial norms)*/) {
+template <int N>
+__device__ void wg_twisted(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f64* zn /*LDS 64 + 64 (partial norms)*/) {
     lds_f64* L = (lds_f64*)lds;
     lds_f64 *dg = L + EIG_TAIL, *e = dg + 128, *lam = dg + 256;
-    lds_f64 *Dp = L, *Dm = L + 64 * EIG_N;                       // [row][lane]
+    lds_f64 *Dp = L, *Dm = L + 64 * 128;                       // [row][lane]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (d_i, e_i) pairs in the reflector scalars' slot are not available: the bisection's pair array lives in L[256..512) = Dp rows
     // 4..7, so the chains read dg / e directly in chunks
     double emax = 0.0;
-    for (int t = 0; t < EIG_N - 1; ++t) emax = fmax(emax, e[t] * e[t]);
+    for (int t = 0; t < N - 1; ++t) emax = fmax(emax, e[t] * e[t]);
     const double pivmin = DBL_MIN * fmax(1.0, emax);
     __syncthreads();                                             // the bisection's arrays (aliasing Dp) are no longer read
     const bool act = lane < r;
     const double lm = lam[act ? lane : 0];
     if (wave == 0) {                                             // D+_0 = d_0 - lam ; D+_i = (d_i - lam) - e_{i-1}^2 / D+_{i-1}
         double q = 1.0;
-        for (int i0 = 0; i0 < EIG_N; i0 += 8) {
+        for (int i0 = 0; i0 < N; i0 += 8) {
             double dd[8], ee[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) { dd[t] = dg[i0 + t]; ee[t] = (i0 + t > 0) ? e[i0 + t - 1] : 0.0; }
@@ -298,10 +308,10 @@ __device__ void wg_twisted128(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f
         }
     } else if (wave == 1) {                                      // D-_{n-1} = d_{n-1} - lam ; D-_i = (d_i - lam) - e_i^2 / D-_{i+1}
         double q = 1.0;
-        for (int i0 = EIG_N - 8; i0 >= 0; i0 -= 8) {
+        for (int i0 = N - 8; i0 >= 0; i0 -= 8) {
             double dd[8], ee[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { dd[t] = dg[i0 + t]; ee[t] = (i0 + t < EIG_N - 1) ? e[i0 + t] : 0.0; }
+            for (int t = 0; t < 8; ++t) { dd[t] = dg[i0 + t]; ee[t] = (i0 + t < N - 1) ? e[i0 + t] : 0.0; }
 #pragma unroll
             for (int t = 7; t >= 0; --t) {
                 q = fma(-(ee[t] * ee[t]), fast_rcp(q), dd[t] - lm);
@@ -315,7 +325,7 @@ __device__ void wg_twisted128(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f
         // twist index: argmin |gamma_i|, gamma_i = D+_i + D-_i - (d_i - lam)   (both waves, redundantly: independent iterations)
         double gbest = 1e300;
         int kb = 0;
-        for (int i = 0; i < EIG_N; ++i) {
+        for (int i = 0; i < N; ++i) {
             const double g = fabs(Dp[i * 64 + lane] + Dm[i * 64 + lane] - (dg[i] - lm));
             if (g < gbest) { gbest = g; kb = i; }
         }
@@ -329,7 +339,7 @@ __device__ void wg_twisted128(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f
             }
             if (act) { tw[lane] = kb; zn[lane] = nrm; }
         } else {
-            for (int i = kb; i < EIG_N - 1; ++i) {
+            for (int i = kb; i < N - 1; ++i) {
                 z = -(e[i] * fast_rcp(Dm[(i + 1) * 64 + lane])) * z;
                 Dm[(i + 1) * 64 + lane] = z;
                 nrm = fma(z, z, nrm);
@@ -343,64 +353,67 @@ __device__ void wg_twisted128(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f
 }
 
 // ---- 4. back-transformation and the driver ----
-// Eigen-decomposition of the symmetric positive definite G (global, column-major, ld 128): the `nev` largest eigenvalues
-// (descending) -> sig[j] = sqrt(lam_j) (global), and the image X (LDS, ld 128): X[j*128 + row] = sqrt(lam_j) * u_j[row] for j < r
-// (r <= 64, r <= nev).  Vst: 128 x 128 doubles of global scratch.  Returns 0, or 1 if a wanted eigenvalue is not positive.
-__device__ __noinline__ int wg_eig128(const double* Gg, double* Vst, int r, int nev, double* sig, double* lds, int* iwork /*LDS 64 ints*/,
-                                      double* dwork /*LDS 64*/, long long* prof) {
+// Eigen-decomposition of the symmetric positive definite N x N matrix G (global, column-major, leading dimension ldg), N = 128 or
+// 64: the `nev` largest eigenvalues (descending) -> sig[j] = sqrt(lam_j) (global), and the image X (LDS, ld 128):
+// X[j*128 + row] = sqrt(lam_j) * u_j[row] for j < r (r <= 64, r <= nev).  Vst: 128 x 128 doubles of global scratch.
+// Returns 0, or 1 if a wanted eigenvalue is not positive.
+template <int N>
+__device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int r, int nev, double* sig, double* lds, int* iwork /*LDS 64 ints*/,
+                                     double* dwork /*LDS 128*/, long long* prof) {
     Gg = unip(Gg); Vst = unip(Vst); sig = unip(sig); lds = unip(lds); iwork = unip(iwork); dwork = unip(dwork);
-    r = uni32(r); nev = uni32(nev);
+    r = uni32(r); nev = uni32(nev); ldg = uni32(ldg);
+    constexpr int RPL = N / 16;                                   // rows per lane in the back-transformation
     lds_f64* L = (lds_f64*)lds;
     lds_f64 *lam = L + EIG_TAIL + 256, *beta = L + EIG_TAIL + 384;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define EIG_MARK(slot) if (prof && threadIdx.x == 0) prof[slot] = (long long)__builtin_amdgcn_s_memtime();
     EIG_MARK(2)
-    wg_tridiag128(Gg, Vst, lds);
+    wg_tridiag<N>(Gg, ldg, Vst, lds);
     EIG_MARK(3)
-    wg_bisect128<8>(nev, lds);
+    wg_bisect<N, 8>(nev, lds);
     // eigenvalues out; all wanted ones must be positive
     int bad = 0;
     for (int j = tid; j < nev; j += TTN_WG) { const double l = lam[j]; sig[j] = (l > 0.0) ? sqrt(l) : 0.0; bad |= !(l > 0.0); }
     if (__syncthreads_or(bad)) return 1;
     EIG_MARK(4)
-    wg_twisted128(r, lds, iwork, (lds_f64*)dwork);
+    wg_twisted<N>(r, lds, iwork, (lds_f64*)dwork);
     EIG_MARK(5)
-    // Z into registers: waves 0..7; a row of 16 lanes owns TWO columns (8 per wave), lane rc of the row holds rows 8*rc .. 8*rc+7
-    // of both — the dot products v_k' z are reductions over the 16 lanes of a row (4 DPP adds each): no LDS reduction and no
-    // barrier in the loop.  The reflectors are staged in LDS once (the D+ / D- arrays are dead after the load of Z).
-    lds_f64 *Dp = L, *Dm = L + 64 * EIG_N;
+    // Z into registers: waves 0..7; a row of 16 lanes owns TWO columns (8 per wave), lane rc of the row holds rows RPL*rc ..
+    // RPL*rc + RPL-1 of both — the dot products v_k' z are reductions over the 16 lanes of a row (4 DPP adds each): no LDS
+    // reduction and no barrier in the loop.  The reflectors are staged in LDS once (the D+ / D- arrays are dead after the load of Z).
+    lds_f64 *Dp = L, *Dm = L + 64 * 128;
     const int rc = lane & 15, col0 = 8 * (wave & 7) + 2 * (lane >> 4);
-    double z[2][8];
+    double z[2][RPL];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
         const int col = col0 + cc;
         const int kb = (col < r) ? iwork[col] : 0;
         const double zn = (col < r) ? ((lds_f64*)dwork)[col] : 0.0;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int row = 8 * rc + t;
+        for (int t = 0; t < RPL; ++t) {
+            const int row = RPL * rc + t;
             const double v = (row < kb) ? Dp[row * 64 + col] : ((row == kb) ? 1.0 : Dm[row * 64 + col]);
             z[cc][t] = v * zn;
         }
     }
     __syncthreads();
-    for (int e_ = tid; e_ < (EIG_N - 2) * 128; e_ += TTN_WG) L[e_] = Vst[e_];
+    for (int e_ = tid; e_ < (N - 2) * 128; e_ += TTN_WG) L[e_] = Vst[e_];
     __syncthreads();
     if (wave < 8) {
         typedef double __attribute__((ext_vector_type(2))) d2;
         typedef __attribute__((address_space(3))) d2 lds_d2;
-        for (int k = EIG_N - 3; k >= 0; --k) {
-            const lds_d2* vp = (const lds_d2*)(L + k * 128 + 8 * rc);
-            double vk[8];
+        for (int k = N - 3; k >= 0; --k) {
+            const lds_d2* vp = (const lds_d2*)(L + k * 128 + RPL * rc);
+            double vk[RPL];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { const d2 w2 = vp[t]; vk[2 * t] = w2.x; vk[2 * t + 1] = w2.y; }
+            for (int t = 0; t < RPL / 2; ++t) { const d2 w2 = vp[t]; vk[2 * t] = w2.x; vk[2 * t + 1] = w2.y; }
             const double bk = beta[k];
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { s0 = fma(vk[t], z[0][t], s0); s1 = fma(vk[t], z[1][t], s1); }
+            for (int t = 0; t < RPL; ++t) { s0 = fma(vk[t], z[0][t], s0); s1 = fma(vk[t], z[1][t], s1); }
             const double t0 = row16_sum(s0) * bk, t1 = row16_sum(s1) * bk;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { z[0][t] = fma(-t0, vk[t], z[0][t]); z[1][t] = fma(-t1, vk[t], z[1][t]); }
+            for (int t = 0; t < RPL; ++t) { z[0][t] = fma(-t0, vk[t], z[0][t]); z[1][t] = fma(-t1, vk[t], z[1][t]); }
         }
     }
     __syncthreads();                                              // everyone has consumed D+ / D-: the image may be written
@@ -412,20 +425,27 @@ __device__ __noinline__ int wg_eig128(const double* Gg, double* Vst, int r, int 
             if (col < r) {
                 const double sg = sig[col];                       // written above by this workgroup, barriers in between
 #pragma unroll
-                for (int t = 0; t < 8; ++t) L[col * 128 + 8 * rc + t] = z[cc][t] * sg;
+                for (int t = 0; t < RPL; ++t) L[col * 128 + RPL * rc + t] = z[cc][t] * sg;
             }
         }
     }
     __syncthreads();
     return 0;
+#undef EIG_MARK
+}
+__device__ int wg_eig128(const double* Gg, double* Vst, int r, int nev, double* sig, double* lds, int* iwork, double* dwork, long long* prof) {
+    return wg_eig_n<128>(Gg, 128, Vst, r, nev, sig, lds, iwork, dwork, prof);
+}
+__device__ int wg_eig64(const double* Gg, int ldg, double* Vst, int r, int nev, double* sig, double* lds, int* iwork, double* dwork) {
+    return wg_eig_n<64>(Gg, ldg, Vst, r, nev, sig, lds, iwork, dwork, nullptr);
 }
 
-__global__ void __launch_bounds__(TTN_WG) k_selftest_eig128(const double* G, double* Vst, int r, int nev, double* sig, double* Xout, long long* clk) {
+__global__ void __launch_bounds__(TTN_WG) k_selftest_eig128(const double* G, double* Vst, int n, int r, int nev, double* sig, double* Xout, long long* clk) {
     extern __shared__ double lds[];
     int* iwork = reinterpret_cast<int*>(lds + GEMM_LDS_TOTAL + 32);
     double* dwork = lds + GEMM_LDS_TOTAL + 32 + 64;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    const int rc = wg_eig128(G, Vst, r, nev, sig, lds, iwork, dwork, clk);
+    const int rc = (n == 64) ? wg_eig_n<64>(G, 64, Vst, r, nev, sig, lds, iwork, dwork, clk) : wg_eig_n<128>(G, 128, Vst, r, nev, sig, lds, iwork, dwork, clk);
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = rc; }
     if (rc == 0) for (int e = threadIdx.x; e < 128 * r; e += TTN_WG) Xout[e] = lds[e];

@@ -20,19 +20,19 @@ for trial in range(4):
     else:
         M = rng.standard_normal((128, 384))
     M /= np.max(np.abs(M))
-    G = np.asfortranarray(M @ M.T)
-    for r, nev in ((64, 64), (64, 128), (17, 40)):
+    for n, r, nev in ((128, 64, 64), (128, 64, 128), (128, 17, 40), (64, 64, 64), (64, 20, 64)):
+        G = np.asfortranarray(M[:n] @ M[:n].T)
         sig = np.zeros(128)
         X = np.zeros((128, 64), order="F")
         tk = (C.c_int64 * 6)()
-        T._lib.check(L.ttn_selftest_eig128(G.ctypes.data_as(C.c_void_p), r, nev, sig.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p), tk))
+        T._lib.check(L.ttn_selftest_eig128(G.ctypes.data_as(C.c_void_p), n, r, nev, sig.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p), tk))
         w, V = np.linalg.eigh(G)
         w, V = w[::-1], V[:, ::-1]
         sref = np.sqrt(w)
         es = np.max(np.abs(sig[:nev] - sref[:nev]) / sref[:nev])
-        Ux = X[:, :r] / sig[:r]
+        Ux = X[:n, :r] / sig[:r]
         orth = np.max(np.abs(Ux.T @ Ux - np.eye(r)))
         resid = np.max(np.abs(G @ Ux - Ux * w[:r]) / w[0])
         sgn = np.sign(np.sum(Ux * V[:, :r], axis=0))
         ev = np.max(np.abs(Ux * sgn - V[:, :r]))
-        print(f"trial {trial} r={r} nev={nev}: rc={tk[1]} ticks={tk[0]} [tridiag {tk[2]} bisect {tk[3]} twisted {tk[4]} back {tk[5]}]  sig rel err {es:.1e}  |U'U-I| {orth:.1e}  resid {resid:.1e}  vec diff {ev:.1e}")
+        print(f"trial {trial} n={n} r={r} nev={nev}: rc={tk[1]} ticks={tk[0]} [tridiag {tk[2]} bisect {tk[3]} twisted {tk[4]} back {tk[5]}]  sig rel err {es:.1e}  |U'U-I| {orth:.1e}  resid {resid:.1e}  vec diff {ev:.1e}")
