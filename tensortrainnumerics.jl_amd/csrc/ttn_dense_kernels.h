@@ -528,33 +528,74 @@ __device__ inline double wave64_sum_fast(double v) {
 // wave w applies H_r to rows r+1+w, r+1+w+16, ...  Writes L (lower triangle, p x min(p,qc)) to dst (row-major, leading
 // dimension ldd); with `full` also zeros above the diagonal up to column p-1 (the L blocks of a TSQR level are read whole).
 // Ss: >= 128 doubles of LDS for the diagonal.  A: the LDS image (>= p*qc doubles).
-__device__ inline void lq_lds_whole(int p, int qc, const double* src, int lds_, double* dst, int ldd, double* A, double* Ss, bool full) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+__device__ inline void lq_lds_whole(int p, int qc, const double* src, int lds_, double* dst, int ldd, double* A_, double* Ss_, bool full) {
+    // LDS address space pointers: through generic pointers every access would be a FLAT instruction
+    lds_f64* A = (lds_f64*)A_;
+    lds_f64* Ss = (lds_f64*)Ss_;
+    const int tid = threadIdx.x;
     const int rr = min(p, qc);
+    // One row per group of 16 lanes (64 rows per pass): the dot product <row_i, v> is a reduction over the 16 lanes of a DPP row
+    // (row16_sum) instead of a whole-wave reduction per row, and the group that updates row r+1 also produces the NEXT reflector's
+    // scalars (beta, tau, scale) as a by-product — nothing in a step is computed redundantly by all waves.
+    const int grp = tid >> 4, l16 = tid & 15;
+    lds_f64* par = Ss + 128;                            // [2][4]: beta, tau, scale of the current / next reflector
     __syncthreads();
     for (int e = tid; e < p * qc; e += TTN_WG) A[e] = src[(long long)(e / qc) * lds_ + (e % qc)];
     __syncthreads();
-    for (int r = 0; r < rr; ++r) {
-        const double* row = A + (long long)r * qc;
+    if (grp == 0) {                                               // reflector 0
         double s = 0.0;
-        for (int c = r + 1 + lane; c < qc; c += 64) { const double v = row[c]; s = fma(v, v, s); }
-        const double xnorm2 = wave64_sum_fast(s);
-        const double alpha = row[r];
+        for (int c = 1 + l16; c < qc; c += 16) { const double v = A[c]; s = fma(v, v, s); }
+        const double xnorm2 = row16_sum(s), alpha = A[0];
         double tau = 0.0, scal = 0.0, beta = alpha;
-        if (xnorm2 > 0.0) {
-            beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha);
-            tau = (beta - alpha) / beta;
-            scal = 1.0 / (alpha - beta);
-        }
+        if (xnorm2 > 0.0) { beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha); tau = (beta - alpha) / beta; scal = 1.0 / (alpha - beta); }
+        if (l16 == 0) { par[0] = beta; par[1] = tau; par[2] = scal; }
+    }
+    __syncthreads();
+    for (int r = 0; r < rr; ++r) {
+        const lds_f64* pr = par + 4 * (r & 1);
+        lds_f64* pn = par + 4 * ((r + 1) & 1);
+        const double beta = pr[0], tau = pr[1], scal = pr[2];
+        const lds_f64* row = A + r * qc;
         if (tid == 0) Ss[r] = beta;
-        for (int i = r + 1 + wave; tau != 0.0 && i < p; i += nwaves) {
-            double* ri = A + (long long)i * qc;
-            double w = 0.0;
-            for (int c = r + 1 + lane; c < qc; c += 64) w = fma(ri[c], row[c], w);
-            w = fma(scal, wave64_sum_fast(w), ri[r]);
-            const double tws = tau * w * scal;
-            for (int c = r + 1 + lane; c < qc; c += 64) ri[c] = fma(-tws, row[c], ri[c]);
-            if (lane == 0) ri[r] -= tau * w;
+        for (int i = r + 1 + grp; i < p; i += TTN_WG / 16) {
+            lds_f64* ri = A + i * qc;
+            // (LDS latency: four independent column groups per trip, so the loads of a trip are in flight together)
+            if (tau != 0.0) {
+                double w = 0.0;
+                for (int c = r + 1 + l16; c < qc; c += 64) {
+                    const bool k1 = c + 16 < qc, k2 = c + 32 < qc, k3 = c + 48 < qc;
+                    const double a0 = ri[c], b0 = row[c];
+                    const double a1 = k1 ? ri[c + 16] : 0.0, b1 = k1 ? row[c + 16] : 0.0;
+                    const double a2 = k2 ? ri[c + 32] : 0.0, b2 = k2 ? row[c + 32] : 0.0;
+                    const double a3 = k3 ? ri[c + 48] : 0.0, b3 = k3 ? row[c + 48] : 0.0;
+                    w = fma(a0, b0, fma(a1, b1, fma(a2, b2, fma(a3, b3, w))));
+                }
+                w = fma(scal, row16_sum(w), ri[r]);
+                const double tws = tau * w * scal;
+                for (int c = r + 1 + l16; c < qc; c += 64) {
+                    const bool k1 = c + 16 < qc, k2 = c + 32 < qc, k3 = c + 48 < qc;
+                    const double a0 = ri[c], b0 = row[c];
+                    const double a1 = k1 ? ri[c + 16] : 0.0, b1 = k1 ? row[c + 16] : 0.0;
+                    const double a2 = k2 ? ri[c + 32] : 0.0, b2 = k2 ? row[c + 32] : 0.0;
+                    const double a3 = k3 ? ri[c + 48] : 0.0, b3 = k3 ? row[c + 48] : 0.0;
+                    ri[c] = fma(-tws, b0, a0);
+                    if (k1) ri[c + 16] = fma(-tws, b1, a1);
+                    if (k2) ri[c + 32] = fma(-tws, b2, a2);
+                    if (k3) ri[c + 48] = fma(-tws, b3, a3);
+                }
+                if (l16 == 0) ri[r] -= tau * w;
+            }
+            if (i == r + 1 && r + 1 < rr) {                        // the next reflector from the freshly updated row r+1
+                double s = 0.0;
+                for (int c = r + 2 + l16; c < qc; c += 64) {
+                    const double v0 = ri[c], v1 = (c + 16 < qc) ? ri[c + 16] : 0.0, v2 = (c + 32 < qc) ? ri[c + 32] : 0.0, v3 = (c + 48 < qc) ? ri[c + 48] : 0.0;
+                    s = fma(v0, v0, fma(v1, v1, fma(v2, v2, fma(v3, v3, s))));
+                }
+                const double xnorm2 = row16_sum(s), alpha = ri[r + 1];
+                double tau2 = 0.0, scal2 = 0.0, beta2 = alpha;
+                if (xnorm2 > 0.0) { beta2 = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha); tau2 = (beta2 - alpha) / beta2; scal2 = 1.0 / (alpha - beta2); }
+                if (l16 == 0) { pn[0] = beta2; pn[1] = tau2; pn[2] = scal2; }
+            }
         }
         __syncthreads();
     }
