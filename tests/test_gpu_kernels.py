@@ -48,3 +48,34 @@ def test_wg_gemm_random_fp64(T):
     got = _gemm(T, A, B, np.zeros((128, 384)), 1.0, 0.0, 0, 0)
     ref = A @ B
     assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref)) * 10
+
+
+# ---- the symmetric eigensolver of the Gram routes (csrc/ttn_eig_kernels.h) ----------------------------------------------------
+@pytest.mark.parametrize("n,r,nev,decades,seed", [(128, 64, 64, 1.5, 0), (128, 64, 128, 2.0, 1), (128, 17, 40, 1.0, 2), (128, 64, 64, 0.0, 3),
+                                                  (64, 64, 64, 1.5, 4), (64, 20, 64, 2.0, 5), (64, 64, 64, 0.0, 6)])
+def test_eig_selftest(n, r, nev, decades, seed):
+    """Tridiagonalisation + bisection + twisted factorisations + back-transformation against numpy.linalg.eigh on Gram matrices
+    shaped like the workload's (smooth spectra over `decades` decades; decades = 0: a plain random Gram matrix).
+    Tolerances: eigenvalues 1e-13 relative to the largest (i.e. singular values to ~1e-13 of the smallest at kappa^2 = 1e4);
+    orthonormality and residual of the returned vectors 1e-11 (the route's a-posteriori limit is 2e-11)."""
+    import ctypes as C
+    import ttn_amd as T
+    T.ensure_init(0)
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((n, 3 * n))
+    if decades > 0:
+        U, s, Vt = np.linalg.svd(M, full_matrices=False)
+        M = (U * (s[0] * 10.0 ** (-decades * np.arange(n) / (n - 1)))) @ Vt
+    M /= np.max(np.abs(M))
+    G = np.asfortranarray(M @ M.T)
+    sig = np.zeros(128)
+    X = np.zeros((128, 64), order="F")
+    tk = (C.c_int64 * 6)()
+    T._lib.check(T._lib.lib().ttn_selftest_eig128(G.ctypes.data_as(C.c_void_p), n, r, nev, sig.ctypes.data_as(C.c_void_p),
+                                                  X.ctypes.data_as(C.c_void_p), tk))
+    assert tk[1] == 0
+    w = np.linalg.eigvalsh(G)[::-1]
+    assert np.max(np.abs(sig[:nev] ** 2 - w[:nev])) <= 1e-13 * w[0]
+    Ux = X[:n, :r] / sig[:r]
+    assert np.max(np.abs(Ux.T @ Ux - np.eye(r))) <= 1e-11
+    assert np.max(np.abs(G @ Ux - Ux * w[:r])) <= 1e-11 * w[0]
