@@ -19,6 +19,9 @@
 //   wg_svd_cols / wg_rank_rule / wg_check_diag, wg_materialize_core / wg_fused_merge, wg_bond_step, k_compress
 //                                   the bond step (routes F / G / H, fused apply) and the persistent sweep kernel
 //   k_dot, k_selftest_gemm, k_bench_gemm, k_bench_lds
+// Sibling headers (included after this one by ttn_api.hip): ttn_eig_kernels.h (symmetric eigensolver of the Gram routes, called
+// from the bond step through the forward declarations below), ttn_ortho_kernels.h, ttn_hsvd_kernels.h (ttv_decomp, SVD moves),
+// ttn_als_kernels.h (als_linsolve / mals_linsolve).
 // Rule learnt the hard way: arguments of out-of-line device functions arrive in VGPRs, and anything
 // loaded from memory the kernel also writes is a per-lane value to the compiler — pin workgroup-uniform values with
 // uni32/uni64/unip, or every derived size, view and pointer occupies VGPRs and ends up in the stack frame.
