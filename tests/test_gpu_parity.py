@@ -727,3 +727,28 @@ def test_randomized_apply_compress_parity(T):
         got = dy.download()
         assert got.ttv_rks == ref.ttv_rks, (it, dims, xr, oprks, mb, te)
         assert tt_rel_diff(to_oracle(got), ref) <= 1e-9, (it, dims, xr, oprks, mb, te)
+
+
+# ---- steps that take the symmetric-eigensolver routes (128-row Gram steps keeping <= 64 vectors, 64 x 64 route-F cores) ----------
+@pytest.mark.parametrize("d,kind,xr,max_bond,truncerr,seed", [(12, 0, 64, 64, 0.0, 0), (13, 0, 64, 50, 0.0, 1), (12, 1, 64, 33, 0.0, 2),
+                                                              (12, 2, 64, 64, 1e-8, 3), (14, 2, 48, 64, 0.0, 4), (12, 0, 64, 20, 1e-12, 5)])
+def test_apply_compress_eigen_routes_vs_oracle(T, d, kind, xr, max_bond, truncerr, seed):
+    """n = 2, rank-64 inputs: the L->R steps merge to 128 x 384 (Gram + eigensolver, csrc/ttn_eig_kernels.h), the R->L steps are
+    route F with a 64 x 64 core (N = 64 eigensolver).  Same tolerances as the other tt_compress! tests: ranks exact, tensors 1e-9."""
+    rng = np.random.default_rng(seed)
+    if kind == 0:
+        A = O.Delta(d)
+    elif kind == 1:
+        A = O.tto_add(O.Delta(d), O.tto_scale(0.7, O.shift(d)))
+    else:
+        A = O.rand_tto((2,) * d, 3, rng)
+    x = O.rand_tt((2,) * d, xr, rng)
+    ref = O.tt_compress_(O.apply(A, x), max_bond, truncerr=truncerr)
+    cap = [a * c for a, c in zip(A.tto_rks, x.ttv_rks)]
+    need, _ = T.device.compress_rank_bound((2,) * d, cap, max_bond)
+    dy = T.DeviceTT((2,) * d, [max(a, b) for a, b in zip(cap, need)])
+    T.device.apply_compress(T.DeviceTTO(to_product(A)), T.DeviceTT.from_host(to_product(x)), dy, max_bond, truncerr)
+    T.device.compress_status(dy)
+    got = dy.download()
+    assert list(got.ttv_rks) == list(ref.ttv_rks)
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
