@@ -15,6 +15,11 @@
 #define EIG_N 128
 // a += (lane J of the caller's row of 16 lanes of w) * s : the DPP form of the fp64 multiply-add broadcasts a lane of each row for
 // free (row_newbcast is the one DPP control 64-bit VALU ops take on gfx90a+), which replaces an LDS broadcast read per operand
+// HAZARD NOTE: gfx9 needs 2 wait states between a VALU write of a VGPR and a DPP read of it, and the compiler does not see the DPP
+// inside this asm.  Every register passed as `w` below is therefore loaded (LDS / memory) and never touched by the VALU before
+// its use, with an s_nop after the loads; a build whose register allocator inserts a copy in between would produce inaccurate
+// eigenpairs, which the routes' a-posteriori check (FAST_CHECK_TOL) turns into a fallback to Householder + Jacobi, not into wrong
+// results.  Putting `s_nop 1` into the asm itself is the belt-and-braces variant (measured: -3 % on the headline).
 template <int J>
 __device__ __forceinline__ void fmac_bcast(double& a, double w, double s_) {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(w), "v"(s_), "n"(J));
