@@ -123,6 +123,7 @@ typedef __attribute__((address_space(3))) int lds_i32;
 // group (meant for the LDS fragment reads) then also waits for the global loads of the NEXT chunk: measured 49 % -> 7x %
 // of the per-CU MFMA peak for the tiled GEMM once the loads are global_load.
 typedef const __attribute__((address_space(1))) double gmem_f64;
+typedef __attribute__((address_space(1))) double gmem_wf64;
 
 // The body is deliberately NOT inlined (17 call sites) and takes its operands through a descriptor in LDS: only two
 // pointers cross the call boundary.
@@ -138,9 +139,15 @@ __device__ inline double unif64(double v) { union { double d; long long i; } u; 
 __device__ inline Idx uniIdx(const Idx& d) { return Idx{uni32(d.q), uni64(d.lo), uni64(d.hi)}; }
 __device__ inline View uniView(const View& v) { return View{(double*)uni64((long long)v.p), uniIdx(v.r), uniIdx(v.c)}; }
 
+// The descriptor lives in LDS: read it through an LDS-address-space pointer (ds_read, ~100 clk and batched) — through the generic
+// pointer the ~25 fields were FLAT loads, 3.5 k clk per GEMM call before the first useful instruction.
+typedef __attribute__((address_space(3))) GemmDesc lds_gdesc;
+__device__ inline Idx ldsIdx(const __attribute__((address_space(3))) Idx* d) { return Idx{uni32(d->q), uni64(d->lo), uni64(d->hi)}; }
+__device__ inline View ldsView(const __attribute__((address_space(3))) View* v) { return View{(double*)uni64((long long)v->p), ldsIdx(&v->r), ldsIdx(&v->c)}; }
+
 // max |C_ij| of the values a GEMM stored, for callers that rescale by it: saves a pass over C (wave max, then one LDS
 // atomic per wave; non-negative doubles order like their bit patterns)
-__device__ inline void gemm_publish_amax(const GemmDesc* dsc, double cmax) {
+__device__ inline void gemm_publish_amax(const lds_gdesc* dsc, double cmax) {
     unsigned long long* am = (unsigned long long*)uni64((long long)dsc->amax);
     if (am) {
         cmax = wave_max(cmax);
@@ -151,14 +158,15 @@ __device__ inline void gemm_publish_amax(const GemmDesc* dsc, double cmax) {
 // WR = wave rows of the 16-wave grid (WR x 16/WR waves, 32x32 outputs per wave): 4 -> 128x128 output tiles, 2 -> 64x256
 // (for m <= 64 and wide n, where half the waves of the square grid would idle).
 template <int WR>
-__device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
+__device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc_, double* lds) {
+    const lds_gdesc* dsc = (const lds_gdesc*)dsc_;
     constexpr int WCN = TTN_NWAVES / WR;                 // wave columns
     constexpr int BM = 32 * WR, BN = 32 * WCN;
     constexpr int LDA = GEMM_LD, LDB = (BN <= 128) ? GEMM_LD : 273;     // both == 17 mod 32 (see GEMM_LD)
     constexpr int STAGE = GEMM_BK * (LDA + LDB);
     static_assert(2 * STAGE <= GEMM_LDS_DOUBLES, "two LDS stages must fit");
     const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
-    const View A = uniView(dsc->A), B = uniView(dsc->B), C = uniView(dsc->C);
+    const View A = ldsView(&dsc->A), B = ldsView(&dsc->B), C = ldsView(&dsc->C);
     const double alpha = unif64(dsc->alpha), beta = unif64(dsc->beta);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WCN, wc = wave % WCN;
@@ -306,7 +314,7 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
                         for (int tj = 0; tj < 2; ++tj) {
                             const int lj_ = wc * 32 + tj * 16 + li;
                             if (n0 + lj_ >= n) continue;
-                            double* cp = C.p + ((long long)ro + colC[lj_]);
+                            gmem_wf64* cp = (gmem_wf64*)C.p + ((long long)ro + colC[lj_]);      // C is always global memory: global_store, not flat
                             double v = alpha * acc[ti][tj][reg];
                             if (beta != 0.0) v += beta * (*cp);
                             *cp = v;
@@ -329,9 +337,10 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc, double* lds) {
 __device__ inline int small_ld(int x) { const int t = (x + 15) & ~15; return (((t & 31) == 16) ? t : t + 16) + 1; }   // == 17 mod 32 (see GEMM_LD)
 __device__ inline int tight_ld(int x) { return ((x + 15) & ~15) + 1; }                                             // odd: conflict-free k-fast stores
 
-__device__ TTN_NI_GEMMS void wg_gemm_small_impl(const GemmDesc* dsc, double* lds) {
+__device__ TTN_NI_GEMMS void wg_gemm_small_impl(const GemmDesc* dsc_, double* lds) {
+    const lds_gdesc* dsc = (const lds_gdesc*)dsc_;
     const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
-    const View A = uniView(dsc->A), B = uniView(dsc->B), C = uniView(dsc->C);
+    const View A = ldsView(&dsc->A), B = ldsView(&dsc->B), C = ldsView(&dsc->C);
     const double alpha = unif64(dsc->alpha), beta = unif64(dsc->beta);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -411,7 +420,7 @@ __device__ TTN_NI_GEMMS void wg_gemm_small_impl(const GemmDesc* dsc, double* lds
         for (int reg = 0; reg < 4; ++reg) {
             const int gi = r0 + lk + 4 * reg, gj = c0 + li;
             if (gi < m && gj < n) {
-                double* cp = C.p + rowC[gi] + colC[gj];
+                gmem_wf64* cp = (gmem_wf64*)C.p + rowC[gi] + colC[gj];
                 double v = alpha * acc[reg];
                 if (beta != 0.0) v += beta * (*cp);
                 *cp = v;
