@@ -58,16 +58,60 @@
 // -------------------------------------------------------------------------------------------------
 // workgroup reductions (1024 threads = 16 waves of 64)
 // -------------------------------------------------------------------------------------------------
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave reductions on DPP row operations + lane reads: __shfl_xor compiles to ds_bpermute (an LDS round trip per step: 1250 clk
+// per 64-lane sum measured with the workgroup busy, 440 for this form).  All 64 lanes must be active.
+template <int CTRL>
+__device__ inline double dpp_mov_f64(double v) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, true);
+    return r.d;
+}
+__device__ inline double row16_sum(double v) {
+    v += dpp_mov_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);    // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);    // row_mirror
     return v;
 }
-__device__ inline double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+__device__ inline double row16_max(double v) {
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    v = fmax(v, dpp_mov_f64<0x140>(v));
     return v;
 }
+__device__ inline double wave64_sum_fast(double v) {
+    v = row16_sum(v);                                   // every lane of a 16-lane row holds the row sum
+    union { double d; int i[2]; } u;
+    u.d = v;
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        union { double d; int i[2]; } w;
+        w.i[0] = __builtin_amdgcn_readlane(u.i[0], 16 * r);
+        w.i[1] = __builtin_amdgcn_readlane(u.i[1], 16 * r);
+        t += w.d;
+    }
+    return t;
+}
+__device__ inline double wave64_max_fast(double v) {
+    v = row16_max(v);
+    union { double d; int i[2]; } u;
+    u.d = v;
+    double t = -1.7976931348623157e308;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        union { double d; int i[2]; } w;
+        w.i[0] = __builtin_amdgcn_readlane(u.i[0], 16 * r);
+        w.i[1] = __builtin_amdgcn_readlane(u.i[1], 16 * r);
+        t = fmax(t, w.d);
+    }
+    return t;
+}
+__device__ inline double wave_sum(double v) { return wave64_sum_fast(v); }
+__device__ inline double wave_max(double v) { return wave64_max_fast(v); }
 // red: LDS scratch of >= 32 doubles.  All threads get the result.
 __device__ inline double wg_sum(double v, double* red) {
     v = wave_sum(v);
@@ -477,22 +521,7 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
     }
 }
 
-template <int CTRL>
-__device__ inline double dpp_mov_f64(double v) {
-    union { double d; int i[2]; } a, r;
-    a.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, true);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, true);
-    return r.d;
-}
 // sum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ inline double row16_sum(double v) {
-    v += dpp_mov_f64<0xB1>(v);     // quad_perm [1,0,3,2]
-    v += dpp_mov_f64<0x4E>(v);     // quad_perm [2,3,0,1]
-    v += dpp_mov_f64<0x141>(v);    // row_half_mirror
-    v += dpp_mov_f64<0x140>(v);    // row_mirror
-    return v;
-}
 __device__ inline double fast_rcp(double x) {       // ~2^-50 relative after one Newton step
     double y = __builtin_amdgcn_rcp(x);
     y = fma(fma(-x, y, 1.0), y, y);
@@ -521,20 +550,6 @@ __device__ inline double fast_rsqrt2(double w) {    // two Newton steps on v_rsq
 // Scratch: Vb (QR_NB x q), Wb (max(p, rr) x QR_NB), Tst (ceil(rr/QR_NB) * QR_NB^2, only with Qout) in global memory;
 // Ts, Ss (QR_NB^2 each), taus (QR_NB), red in LDS behind the GEMM region.
 // -------------------------------------------------------------------------------------------------
-__device__ inline double wave64_sum_fast(double v) {
-    v = row16_sum(v);                                   // every lane of a 16-lane row holds the row sum
-    union { double d; int i[2]; } u;
-    u.d = v;
-    double t = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        union { double d; int i[2]; } w;
-        w.i[0] = __builtin_amdgcn_readlane(u.i[0], 16 * r);
-        w.i[1] = __builtin_amdgcn_readlane(u.i[1], 16 * r);
-        t += w.d;
-    }
-    return t;
-}
 
 // Householder LQ of a p x qc matrix (row-major, leading dimension lds_) entirely in LDS: p reflectors, one barrier each,
 // wave w applies H_r to rows r+1+w, r+1+w+16, ...  Writes L (lower triangle, p x min(p,qc)) to dst (row-major, leading
