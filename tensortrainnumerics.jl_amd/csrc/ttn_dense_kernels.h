@@ -567,7 +567,9 @@ __device__ inline void lq_lds_whole(int p, int qc, const double* src, int lds_, 
     const int grp = tid >> 4, l16 = tid & 15;
     lds_f64* par = Ss + 128;                            // [2][4]: beta, tau, scale of the current / next reflector
     __syncthreads();
-    for (int e = tid; e < p * qc; e += TTN_WG) A[e] = src[(long long)(e / qc) * lds_ + (e % qc)];
+    gmem_f64* srcg = (gmem_f64*)src;                              // M2 is global memory: global_load / global_store, not FLAT
+    gmem_wf64* dstg = (gmem_wf64*)dst;
+    for (int e = tid; e < p * qc; e += TTN_WG) A[e] = srcg[(long long)(e / qc) * lds_ + (e % qc)];
     __syncthreads();
     if (grp == 0) {                                               // reflector 0
         double s = 0.0;
@@ -629,8 +631,8 @@ __device__ inline void lq_lds_whole(int p, int qc, const double* src, int lds_, 
     const int ncol = full ? p : rr;
     for (int e = tid; e < p * ncol; e += TTN_WG) {
         const int r = e / ncol, c = e % ncol;
-        if (c <= r && c < rr) dst[(long long)r * ldd + c] = (c == r) ? Ss[r] : A[(long long)r * qc + c];
-        else if (full) dst[(long long)r * ldd + c] = 0.0;
+        if (c <= r && c < rr) dstg[(long long)r * ldd + c] = (c == r) ? Ss[r] : A[r * qc + c];
+        else if (full) dstg[(long long)r * ldd + c] = 0.0;
     }
     __syncthreads();
 }
@@ -1081,6 +1083,7 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
     constexpr int G = 4;                                // lane groups per wave = columns per block
     constexpr int CH = 32;                              // doubles per 16-byte-per-lane piece of a column
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
+    lds_i32* flagL = (lds_i32*)flag;                    // the convergence flag lives in LDS: ds ops, not FLAT ones through the generic pointer
     const int grp = (lane >> 2) & 3;
     const int sub = (lane & 3) | ((lane >> 4) << 2);
     const int roff = 2 * sub;                           // row offset inside a piece
@@ -1115,7 +1118,7 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
                 if (tid == 0) *aneg_out = aneg;
             }
         }
-        if (tid == 0) *flag = 0;
+        if (tid == 0) *flagL = 0;
         __syncthreads();
         int rotated = 0;
         // Block ordering.  The columns form nb blocks of 4 (nbp = nb rounded up to a power of two, phantom blocks idle).
@@ -1271,9 +1274,9 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
         }
 #undef JROT_MATH
 #undef JOFF
-        if (rotated) *flag = 1;
+        if (rotated) *flagL = 1;
         __syncthreads();
-        const int any = *flag;
+        const int any = *flagL;
         __syncthreads();
         if (!any) return sweep + 1;
     }
