@@ -39,6 +39,14 @@ __device__ __forceinline__ void fmac_bcast(double& a, double w, double s_) {
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding GLOBAL stores (the
 // reflector rows written to Vst for the back-transformation), ~1 k clk per column of the tridiagonalisation for nothing.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// 64-lane sum, result in every lane: two v_mfma_f64_4x4x4 against ones reduce the 16 lanes that share a quad position (grp_sum,
+// ttn_dense_kernels.h), two DPP row rotations add the four quad positions.  Whole-wave control flow only.
+__device__ __forceinline__ double wave64_sum_mfma(double v) {
+    v = grp_sum(v);
+    v += dpp_mov_f64<0x124>(v);      // row_ror:4
+    v += dpp_mov_f64<0x128>(v);      // row_ror:8
+    return v;
+}
 // lane `idx` (wave-uniform) of a double
 __device__ __forceinline__ double readlane_f64(double v, int idx) {
     union { double d; int i[2]; } u, r;
@@ -50,7 +58,7 @@ __device__ __forceinline__ double readlane_f64(double v, int idx) {
 __device__ __forceinline__ void tridiag_reflector(int k, double x0, double x1, double xk1, int lane, lds_f64* vbuf, double* Vst,
                                                   lds_f64* dg, lds_f64* e, lds_f64* beta, double dgk) {
     // lanes hold entries lane, lane + 64 of column k (zero at and above the diagonal position k)
-    const double s2 = wave64_sum_fast(fma(x0, x0, x1 * x1));
+    const double s2 = wave64_sum_mfma(fma(x0, x0, x1 * x1));
     // sqrt and reciprocal from the hardware seeds + Newton steps (full fp64 accuracy; this chain is on the critical path)
     const double alpha = (s2 > 0.0) ? -copysign(s2 * fast_rsqrt2(s2), xk1) : 0.0;
     const double den = s2 - alpha * xk1;                           // = v'v / 2
@@ -118,7 +126,7 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) { p0 += part[cc * 128 + lane]; if (TWO) p1 += part[cc * 128 + lane + 64]; }
             p0 *= bta; p1 *= bta;
-            const double Kc = 0.5 * bta * wave64_sum_fast(fma(p0, v0, p1 * v1));
+            const double Kc = 0.5 * bta * wave64_sum_mfma(fma(p0, v0, p1 * v1));
             w0 = fma(-Kc, v0, p0); w1 = fma(-Kc, v1, p1);
             wL[lane] = w0; if (TWO) wL[lane + 64] = w1;
         }
@@ -126,6 +134,19 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
         // row k+2 of the UPDATED matrix goes to the look-ahead buffer the next step reads (two buffers alternate)
         lds_f64* xn_r = (k & 1) ? xnext + 1152 : xnext;          // read this step (row k+1 before update k)
         lds_f64* xn_w = (k & 1) ? xnext : xnext + 1152;          // written this step (row k+2 after update k)
+        // wave 0 first forms the next reflector (the other waves are busy with their share of the update meanwhile), then its own share
+        if (wave == 0 && k + 1 < N - 2) {
+            // column k+1 of the updated matrix: x - v w_{k+1} - w v_{k+1}, then reflector k+1 (entries <= k+1 are not part of it)
+            const double wk1 = wL[k + 1], vk1 = vL[k + 1];
+            const double c0 = fma(-v0, wk1, fma(-w0, vk1, xn_r[lane]));
+            const double c1 = TWO ? fma(-v1, wk1, fma(-w1, vk1, xn_r[lane + 64])) : 0.0;
+            // entries k+1 (the new diagonal) and k+2 by lane reads
+            const int kk = k + 1;
+            const double dgk = (kk < 64) ? readlane_f64(c0, kk) : readlane_f64(c1, kk - 64);
+            const double xk1 = (kk + 1 < 64) ? readlane_f64(c0, kk + 1) : readlane_f64(c1, kk + 1 - 64);
+            const double x0 = (lane > kk) ? c0 : 0.0, x1 = (TWO && lane + 64 > kk) ? c1 : 0.0;
+            tridiag_reflector(kk, x0, x1, xk1, lane, vN, Vst, dg, e, beta, dgk);
+        }
         if (actv) {
             // A -= v w' + w v'
             const double wreg = wL[16 * c + (lane & 15)];
@@ -138,18 +159,6 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
 #pragma unroll
                 for (int j = 0; j < 16; ++j) xn_w[16 * c + j] = a[j];
             }
-        }
-        if (wave == 0 && k + 1 < N - 2) {
-            // column k+1 of the updated matrix: x - v w_{k+1} - w v_{k+1}, then reflector k+1 (entries <= k+1 are not part of it)
-            const double wk1 = wL[k + 1], vk1 = vL[k + 1];
-            const double c0 = fma(-v0, wk1, fma(-w0, vk1, xn_r[lane]));
-            const double c1 = TWO ? fma(-v1, wk1, fma(-w1, vk1, xn_r[lane + 64])) : 0.0;
-            // entries k+1 (the new diagonal) and k+2 by lane reads
-            const int kk = k + 1;
-            const double dgk = (kk < 64) ? readlane_f64(c0, kk) : readlane_f64(c1, kk - 64);
-            const double xk1 = (kk + 1 < 64) ? readlane_f64(c0, kk + 1) : readlane_f64(c1, kk + 1 - 64);
-            const double x0 = (lane > kk) ? c0 : 0.0, x1 = (TWO && lane + 64 > kk) ? c1 : 0.0;
-            tridiag_reflector(kk, x0, x1, xk1, lane, vN, Vst, dg, e, beta, dgk);
         }
     }
     // the last 2 x 2 block
