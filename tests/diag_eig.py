@@ -20,7 +20,7 @@ for trial in range(4):
     else:
         M = rng.standard_normal((128, 384))
     M /= np.max(np.abs(M))
-    for n, r, nev in ((128, 64, 64), (128, 64, 128), (128, 17, 40), (64, 64, 64), (64, 20, 64)):
+    for n, r, nev in ((128, 64, 64), (128, 64, 128), (128, 17, 40), (64, 64, 64), (64, 20, 64), (64, 32, 32), (64, 5, 9)):
         G = np.asfortranarray(M[:n] @ M[:n].T)
         sig = np.zeros(128)
         X = np.zeros((128, 64), order="F")
