@@ -1960,7 +1960,8 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         // small merged matrices (the rank-ramp steps) fit the LDS whole: their Householder LQ needs no GEMM calls and costs
         // about what the Gram + Cholesky do, without the conditioning gamble — route H directly
         const bool lq_in_lds = (long long)p * q <= GEMM_LDS_DOUBLES || GEMM_LDS_DOUBLES / p >= 2 * p;     // whole, or TSQR chunks (wg_lq_blocked)
-        for (int attempt = (SWAP == 0 && P.fast && need_lq && x_in_lds && p >= 2 && !lq_in_lds) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
+        const bool eig_ok = SWAP == 0 && P.fast && !(P.fast & 2) && need_lq && ((p == 128 && P.max_bond <= 64) || (p == 64 && P.max_bond < 64));
+        for (int attempt = (SWAP == 0 && P.fast && need_lq && x_in_lds && p >= 2 && (!lq_in_lds || eig_ok)) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
             bool ok = true;
             bool use_eig = false;
             if (attempt == 1) {
@@ -1970,13 +1971,14 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 // p = 128 with at most 64 vectors kept (the L->R steps of the benchmark sweep): eigen-decomposition of the Gram
                 // matrix itself — tridiagonalisation, bisection, twisted factorisations (ttn_eig_kernels.h) — instead of
                 // Cholesky + Jacobi on L; same outputs (sigs, perm, X = sigma_j u_j in LDS), same a-posteriori check below
-                use_eig = (p == 128) && !(P.fast & 2) && P.max_bond <= 64;
+                use_eig = eig_ok;
                 if (use_eig) {
                     const int r0 = (int)P.max_bond;
-                    const int nev = (P.truncerr > 0.0 || (P.sv_out && step < P.sv_steps)) ? 128 : r0;
-                    ok = wg_eig128(S.Ga, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64, nullptr) == 0;
-                    for (int j = tid; j < 128; j += TTN_WG) { S.perm[j] = j; if (j >= nev) S.sigs[j] = 0.0; }
-                    if (tid == 0) S.scal[0] = P.jneg_mult * P.jneg_mult * 128.0 * DBL_EPSILON * DBL_EPSILON * S.sigs[0] * S.sigs[0];
+                    const int nev = (P.truncerr > 0.0 || (P.sv_out && step < P.sv_steps)) ? p : r0;
+                    ok = ((p == 64) ? wg_eig64(S.Ga, 128, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64)
+                                    : wg_eig128(S.Ga, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64, nullptr)) == 0;
+                    for (int j = tid; j < p; j += TTN_WG) { S.perm[j] = j; if (j >= nev) S.sigs[j] = 0.0; }      // (sigs / perm hold pmax entries)
+                    if (tid == 0) S.scal[0] = P.jneg_mult * P.jneg_mult * (double)p * DBL_EPSILON * DBL_EPSILON * S.sigs[0] * S.sigs[0];
                     __syncthreads();
                     PROF_MARK(11)
                 } else {
