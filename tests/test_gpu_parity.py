@@ -731,10 +731,11 @@ def test_randomized_apply_compress_parity(T):
 
 # ---- steps that take the symmetric-eigensolver routes (128-row Gram steps keeping <= 64 vectors, 64 x 64 route-F cores) ----------
 @pytest.mark.parametrize("d,kind,xr,max_bond,truncerr,seed", [(12, 0, 64, 64, 0.0, 0), (13, 0, 64, 50, 0.0, 1), (12, 1, 64, 33, 0.0, 2),
-                                                              (12, 2, 64, 64, 1e-8, 3), (14, 2, 48, 64, 0.0, 4), (12, 0, 64, 20, 1e-12, 5)])
+                                                              (12, 2, 64, 64, 1e-8, 3), (14, 2, 48, 64, 0.0, 4), (12, 0, 64, 20, 1e-12, 5),
+                                                              (12, 0, 32, 32, 0.0, 6), (13, 2, 32, 20, 1e-8, 7), (12, 1, 32, 31, 0.0, 8)])
 def test_apply_compress_eigen_routes_vs_oracle(T, d, kind, xr, max_bond, truncerr, seed):
     """n = 2, rank-64 inputs: the L->R steps merge to 128 x 384 (Gram + eigensolver, csrc/ttn_eig_kernels.h), the R->L steps are
-    route F with a 64 x 64 core (N = 64 eigensolver).  Same tolerances as the other tt_compress! tests: ranks exact, tensors 1e-9."""
+    route F with a 64 x 64 core (N = 64 eigensolver); rank-32 inputs: 64 x 192 Gram steps on the N = 64 eigensolver.  Same tolerances as the other tt_compress! tests: ranks exact, tensors 1e-9."""
     rng = np.random.default_rng(seed)
     if kind == 0:
         A = O.Delta(d)
