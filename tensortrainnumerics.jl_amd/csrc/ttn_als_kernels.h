@@ -31,25 +31,31 @@ struct AlsArgs {
 // GEMM (wg_gemm, alpha = -1, beta = 1) — that GEMM carries the 2/3 N^3 flops.  The right-hand side is eliminated on the fly;
 // back substitution at the end.  Returns 0, or 1 if a pivot is exactly zero (LAPACK: SingularException).
 #define LU_NB 32
-__device__ __noinline__ int wg_lu_solve(int N, double* K, double* rhs, int* piv, double* red, int* iflag, double* lds) {
-    N = uni32(N); K = unip(K); rhs = unip(rhs); piv = unip(piv); red = unip(red); iflag = unip(iflag); lds = unip(lds);
+__device__ __noinline__ int wg_lu_solve(int N, double* K_, double* rhs_, int* piv_, double* red, int* iflag_, double* lds) {
+    N = uni32(N); K_ = unip(K_); rhs_ = unip(rhs_); piv_ = unip(piv_); red = unip(red); iflag_ = unip(iflag_); lds = unip(lds);
+    // typed address spaces: through the generic pointers every access below was a FLAT instruction
+    typedef __attribute__((address_space(1))) int gmem_i32;
+    gmem_wf64* K = (gmem_wf64*)K_;
+    gmem_wf64* rhs = (gmem_wf64*)rhs_;
+    gmem_i32* piv = (gmem_i32*)piv_;
+    lds_i32* iflag = (lds_i32*)iflag_;
     const int tid = threadIdx.x;
     for (int k0 = 0; k0 < N; k0 += LU_NB) {
         const int w = min(LU_NB, N - k0);
         // ---- (a) the panel, column by column ----
         for (int j = k0; j < k0 + w; ++j) {
-            double* colj = K + (long long)j * N;
+            gmem_wf64* colj = K + (long long)j * N;
             double vm = 0.0;
             for (int i = j + tid; i < N; i += TTN_WG) vm = fmax(vm, fabs(colj[i]));
             if (tid == 0) iflag[0] = N;
             vm = unif64(wg_max(vm, red));                   // barriers inside: iflag[0] is visible after it
             if (!(vm > 0.0)) return 1;
-            for (int i = j + tid; i < N; i += TTN_WG) if (fabs(colj[i]) == vm) atomicMin(&iflag[0], i);
+            for (int i = j + tid; i < N; i += TTN_WG) if (fabs(colj[i]) == vm) atomicMin((int*)iflag_, i);
             __syncthreads();
             const int pv = uni32(iflag[0]);
             if (tid == 0) piv[j] = pv;
             if (pv != j && tid < w) {                        // interchange inside the panel now, outside it in (b)
-                double* c = K + (long long)(k0 + tid) * N;
+                gmem_wf64* c = K + (long long)(k0 + tid) * N;
                 const double t = c[j]; c[j] = c[pv]; c[pv] = t;
             }
             __syncthreads();
@@ -66,7 +72,7 @@ __device__ __noinline__ int wg_lu_solve(int N, double* K, double* rhs, int* piv,
         // ---- (b) the panel's interchanges on the other columns (a thread owns a column: order kept) and on the rhs ----
         for (int c = tid; c < N + 1; c += TTN_WG) {
             if (c >= k0 && c < k0 + w) continue;
-            double* col = (c == N) ? rhs : K + (long long)c * N;
+            gmem_wf64* col = (c == N) ? rhs : K + (long long)c * N;
             for (int j = k0; j < k0 + w; ++j) {
                 const int pv = piv[j];
                 if (pv != j) { const double t = col[j]; col[j] = col[pv]; col[pv] = t; }
@@ -82,7 +88,7 @@ __device__ __noinline__ int wg_lu_solve(int N, double* K, double* rhs, int* piv,
         }
         __syncthreads();
         for (int c = k0 + w + tid; c < N + 1; c += TTN_WG) {
-            double* col = (c == N) ? rhs : K + (long long)c * N;
+            gmem_wf64* col = (c == N) ? rhs : K + (long long)c * N;
             double u[LU_NB];
 #pragma unroll
             for (int ii = 0; ii < LU_NB; ++ii) u[ii] = (ii < w) ? col[k0 + ii] : 0.0;
@@ -104,15 +110,15 @@ __device__ __noinline__ int wg_lu_solve(int N, double* K, double* rhs, int* piv,
                 rhs[i] = a;
             }
             // ---- (d) A22 -= L21 U12 ----
-            const View L21 = mkview(K + (long long)k0 * N + (k0 + w), plain(1), plain(N));                 // m x w
-            const View U12 = mkview(K + (long long)(k0 + w) * N + k0, plain(1), plain(N));                 // w x m
-            const View A22 = mkview(K + (long long)(k0 + w) * N + (k0 + w), plain(1), plain(N));           // m x m
+            const View L21 = mkview(K_ + (long long)k0 * N + (k0 + w), plain(1), plain(N));                 // m x w
+            const View U12 = mkview(K_ + (long long)(k0 + w) * N + k0, plain(1), plain(N));                 // w x m
+            const View A22 = mkview(K_ + (long long)(k0 + w) * N + (k0 + w), plain(1), plain(N));           // m x m
             wg_gemm(m, m, w, L21, U12, A22, -1.0, 1.0, lds);
         }
         __syncthreads();
     }
     for (int k = N - 1; k >= 0; --k) {                       // back substitution with U
-        const double* colk = K + (long long)k * N;
+        const gmem_wf64* colk = K + (long long)k * N;
         const double xk = rhs[k] / colk[k];
         __syncthreads();
         if (tid == 0) rhs[k] = xk;
