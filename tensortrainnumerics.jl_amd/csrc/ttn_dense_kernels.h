@@ -640,61 +640,96 @@ __device__ inline void lq_lds_whole(int p, int qc, const double* src, int lds_, 
 // The same with the explicit thin Q' (p x q, orthonormal rows, M = L Q'): factor in LDS, then E = [I 0] times
 // H_{p-1} ... H_0 in a second LDS image (2*p*q doubles in all: 64x128 cores of rank-64 trains fit).  In place: M2 receives L.
 // Ts (>= 128 doubles): tau_r; Ss (>= 256 doubles): beta_r and the scale 1/(alpha - beta) of the stored reflectors.
-__device__ inline void lq_lds_whole_q(int p, int q, double* M2, int ld, double* Qout, double* A, double* Ss, double* Ts) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
-    double* E = A + (long long)p * q;
-    double* scl = Ss + 128;
+__device__ inline void lq_lds_whole_q(int p, int q, double* M2, int ld, double* Qout, double* A_, double* Ss_, double* Ts_) {
+    // same organisation as lq_lds_whole: LDS address-space pointers (no FLAT instructions), one row per group of 16 lanes with DPP
+    // row sums, the next reflector's scalars as a by-product of the update of row r+1
+    const int tid = threadIdx.x;
+    const int grp = tid >> 4, l16 = tid & 15;
+    lds_f64* A = (lds_f64*)A_;
+    lds_f64* Ss = (lds_f64*)Ss_;
+    lds_f64* Ts = (lds_f64*)Ts_;
+    lds_f64* E = A + p * q;
+    lds_f64* scl = Ss + 128;
+    lds_f64* par = Ts + 128;                                      // [2][4]: beta, tau, scale of the current / next reflector
+    gmem_wf64* M2g = (gmem_wf64*)M2;
+    gmem_wf64* Qg = (gmem_wf64*)Qout;
     __syncthreads();
     for (int e = tid; e < p * q; e += TTN_WG) {
         const int r = e / q, c = e % q;
-        A[e] = M2[(long long)r * ld + c];
+        A[e] = M2g[(long long)r * ld + c];
         E[e] = (r == c) ? 1.0 : 0.0;
     }
     __syncthreads();
-    for (int r = 0; r < p; ++r) {
-        const double* row = A + (long long)r * q;
+    if (grp == 0) {
         double s = 0.0;
-        for (int c = r + 1 + lane; c < q; c += 64) { const double v = row[c]; s = fma(v, v, s); }
-        const double xnorm2 = wave64_sum_fast(s);
-        const double alpha = row[r];
+        for (int c = 1 + l16; c < q; c += 16) { const double v = A[c]; s = fma(v, v, s); }
+        const double xnorm2 = row16_sum(s), alpha = A[0];
         double tau = 0.0, scal = 0.0, beta = alpha;
-        if (xnorm2 > 0.0) {
-            beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha);
-            tau = (beta - alpha) / beta;
-            scal = 1.0 / (alpha - beta);
-        }
+        if (xnorm2 > 0.0) { beta = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha); tau = (beta - alpha) / beta; scal = 1.0 / (alpha - beta); }
+        if (l16 == 0) { par[0] = beta; par[1] = tau; par[2] = scal; }
+    }
+    __syncthreads();
+    for (int r = 0; r < p; ++r) {
+        const lds_f64* pr = par + 4 * (r & 1);
+        lds_f64* pn = par + 4 * ((r + 1) & 1);
+        const double beta = pr[0], tau = pr[1], scal = pr[2];
+        const lds_f64* row = A + r * q;
         if (tid == 0) { Ss[r] = beta; scl[r] = scal; Ts[r] = tau; }
-        for (int i = r + 1 + wave; tau != 0.0 && i < p; i += nwaves) {
-            double* ri = A + (long long)i * q;
-            double w = 0.0;
-            for (int c = r + 1 + lane; c < q; c += 64) w = fma(ri[c], row[c], w);
-            w = fma(scal, wave64_sum_fast(w), ri[r]);
-            const double tws = tau * w * scal;
-            for (int c = r + 1 + lane; c < q; c += 64) ri[c] = fma(-tws, row[c], ri[c]);
-            if (lane == 0) ri[r] -= tau * w;
+        for (int i = r + 1 + grp; i < p; i += TTN_WG / 16) {
+            lds_f64* ri = A + i * q;
+            if (tau != 0.0) {
+                double w = 0.0;
+                for (int c = r + 1 + l16; c < q; c += 64) {
+                    const bool k1 = c + 16 < q, k2 = c + 32 < q, k3 = c + 48 < q;
+                    const double a0 = ri[c], b0 = row[c];
+                    const double a1 = k1 ? ri[c + 16] : 0.0, b1 = k1 ? row[c + 16] : 0.0;
+                    const double a2 = k2 ? ri[c + 32] : 0.0, b2 = k2 ? row[c + 32] : 0.0;
+                    const double a3 = k3 ? ri[c + 48] : 0.0, b3 = k3 ? row[c + 48] : 0.0;
+                    w = fma(a0, b0, fma(a1, b1, fma(a2, b2, fma(a3, b3, w))));
+                }
+                w = fma(scal, row16_sum(w), ri[r]);
+                const double tws = tau * w * scal;
+                for (int c = r + 1 + l16; c < q; c += 16) ri[c] = fma(-tws, row[c], ri[c]);
+                if (l16 == 0) ri[r] -= tau * w;
+            }
+            if (i == r + 1 && r + 1 < p) {
+                double s = 0.0;
+                for (int c = r + 2 + l16; c < q; c += 16) { const double v = ri[c]; s = fma(v, v, s); }
+                const double xnorm2 = row16_sum(s), alpha = ri[r + 1];
+                double tau2 = 0.0, scal2 = 0.0, beta2 = alpha;
+                if (xnorm2 > 0.0) { beta2 = -copysign(sqrt(fma(alpha, alpha, xnorm2)), alpha); tau2 = (beta2 - alpha) / beta2; scal2 = 1.0 / (alpha - beta2); }
+                if (l16 == 0) { pn[0] = beta2; pn[1] = tau2; pn[2] = scal2; }
+            }
         }
         __syncthreads();
     }
     for (int e = tid; e < p * p; e += TTN_WG) {                 // L into M2 (the caller reads c <= r only)
         const int r = e / p, c = e % p;
-        if (c <= r) M2[(long long)r * ld + c] = (c == r) ? Ss[r] : A[(long long)r * q + c];
+        if (c <= r) M2g[(long long)r * ld + c] = (c == r) ? Ss[r] : A[r * q + c];
     }
     // E <- E H_r for r = p-1 .. 0: rows i < r are still unit vectors orthogonal to v_r, so only rows i >= r change
     for (int r = p - 1; r >= 0; --r) {
-        const double* row = A + (long long)r * q;               // v_r = [0.., 1 at r, row[c] * scl[r] for c > r]
+        const lds_f64* row = A + r * q;                          // v_r = [0.., 1 at r, row[c] * scl[r] for c > r]
         const double tau = Ts[r], sc = scl[r];
-        for (int i = r + wave; tau != 0.0 && i < p; i += nwaves) {
-            double* ei = E + (long long)i * q;
+        for (int i = r + grp; tau != 0.0 && i < p; i += TTN_WG / 16) {
+            lds_f64* ei = E + i * q;
             double w = 0.0;
-            for (int c = r + 1 + lane; c < q; c += 64) w = fma(ei[c], row[c], w);
-            w = fma(sc, wave64_sum_fast(w), ei[r]);
+            for (int c = r + 1 + l16; c < q; c += 64) {
+                const bool k1 = c + 16 < q, k2 = c + 32 < q, k3 = c + 48 < q;
+                const double a0 = ei[c], b0 = row[c];
+                const double a1 = k1 ? ei[c + 16] : 0.0, b1 = k1 ? row[c + 16] : 0.0;
+                const double a2 = k2 ? ei[c + 32] : 0.0, b2 = k2 ? row[c + 32] : 0.0;
+                const double a3 = k3 ? ei[c + 48] : 0.0, b3 = k3 ? row[c + 48] : 0.0;
+                w = fma(a0, b0, fma(a1, b1, fma(a2, b2, fma(a3, b3, w))));
+            }
+            w = fma(sc, row16_sum(w), ei[r]);
             const double tws = tau * w * sc;
-            for (int c = r + 1 + lane; c < q; c += 64) ei[c] = fma(-tws, row[c], ei[c]);
-            if (lane == 0) ei[r] -= tau * w;
+            for (int c = r + 1 + l16; c < q; c += 16) ei[c] = fma(-tws, row[c], ei[c]);
+            if (l16 == 0) ei[r] -= tau * w;
         }
         __syncthreads();
     }
-    for (int e = tid; e < p * q; e += TTN_WG) Qout[e] = E[e];
+    for (int e = tid; e < p * q; e += TTN_WG) Qg[e] = E[e];
     __syncthreads();
 }
 
