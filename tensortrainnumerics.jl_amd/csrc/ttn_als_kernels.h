@@ -42,7 +42,42 @@ __device__ __noinline__ int wg_lu_solve(int N, double* K_, double* rhs_, int* pi
     const int tid = threadIdx.x;
     for (int k0 = 0; k0 < N; k0 += LU_NB) {
         const int w = min(LU_NB, N - k0);
-        // ---- (a) the panel, column by column ----
+        // ---- (a) the panel, column by column.  A panel of at most 16384 doubles is factored in LDS (every access of the
+        //      column loop is then an LDS access instead of a global-memory round trip: the loop is latency bound) ----
+        const int mrows = N - k0;
+        const bool pan_lds = (long long)mrows * LU_NB <= 128 * 128;
+        if (pan_lds) {
+            lds_f64* Pn = (lds_f64*)lds;
+            const int ldp = mrows | 1;                            // odd leading dimension
+            for (int e = tid; e < mrows * w; e += TTN_WG) { const int c = e / mrows, i = e - c * mrows; Pn[c * ldp + i] = K[(long long)(k0 + c) * N + k0 + i]; }
+            __syncthreads();
+            for (int jl = 0; jl < w; ++jl) {
+                lds_f64* colj = Pn + jl * ldp;
+                double vm = 0.0;
+                for (int i = jl + tid; i < mrows; i += TTN_WG) vm = fmax(vm, fabs(colj[i]));
+                if (tid == 0) iflag[0] = N;
+                vm = unif64(wg_max(vm, red));
+                if (!(vm > 0.0)) return 1;
+                for (int i = jl + tid; i < mrows; i += TTN_WG) if (fabs(colj[i]) == vm) atomicMin((int*)iflag_, i);
+                __syncthreads();
+                const int pvl = uni32(iflag[0]);
+                if (tid == 0) piv[k0 + jl] = k0 + pvl;
+                if (pvl != jl && tid < w) { lds_f64* c = Pn + tid * ldp; const double t = c[jl]; c[jl] = c[pvl]; c[pvl] = t; }
+                __syncthreads();
+                const double pivot = colj[jl];
+                __syncthreads();                                  // everybody has the pivot before column jl is scaled
+                for (int i = jl + 1 + tid; i < mrows; i += TTN_WG) colj[i] = colj[i] / pivot;
+                __syncthreads();
+                const int m = mrows - jl - 1, nc = w - jl - 1;
+                for (int e = tid; e < m * nc; e += TTN_WG) {
+                    const int i = jl + 1 + e % m, c = jl + 1 + e / m;
+                    Pn[c * ldp + i] = fma(-colj[i], Pn[c * ldp + jl], Pn[c * ldp + i]);
+                }
+                __syncthreads();
+            }
+            for (int e = tid; e < mrows * w; e += TTN_WG) { const int c = e / mrows, i = e - c * mrows; K[(long long)(k0 + c) * N + k0 + i] = Pn[c * ldp + i]; }
+            __syncthreads();
+        } else
         for (int j = k0; j < k0 + w; ++j) {
             gmem_wf64* colj = K + (long long)j * N;
             double vm = 0.0;
@@ -117,13 +152,34 @@ __device__ __noinline__ int wg_lu_solve(int N, double* K_, double* rhs_, int* pi
         }
         __syncthreads();
     }
-    for (int k = N - 1; k >= 0; --k) {                       // back substitution with U
-        const gmem_wf64* colk = K + (long long)k * N;
-        const double xk = rhs[k] / colk[k];
-        __syncthreads();
-        if (tid == 0) rhs[k] = xk;
-        for (int i = tid; i < k; i += TTN_WG) rhs[i] = fma(-colk[i], xk, rhs[i]);
-        __syncthreads();
+    // back substitution with U, in blocks of 32 unknowns: the triangular block is solved in LDS by wave 0, the rows above it take
+    // the block's contribution in parallel (same operations in the same order as the unblocked loop, one global round trip per
+    // block instead of one per unknown)
+    {
+        lds_f64* Ub = (lds_f64*)lds;                              // [c * 33 + r], r <= c
+        lds_f64* yb = Ub + 33 * 32;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int kb = ((N - 1) / 32) * 32; kb >= 0; kb -= 32) {
+            const int wb = min(32, N - kb);
+            for (int e = tid; e < wb * wb; e += TTN_WG) { const int c = e / wb, r_ = e - c * wb; if (r_ <= c) Ub[c * 33 + r_] = K[(long long)(kb + c) * N + kb + r_]; }
+            if (tid < wb) yb[tid] = rhs[kb + tid];
+            __syncthreads();
+            if (wave == 0) {
+                for (int c = wb - 1; c >= 0; --c) {
+                    const double xc = yb[c] / Ub[c * 33 + c];
+                    if (lane < c) yb[lane] = fma(-Ub[c * 33 + lane], xc, yb[lane]);
+                    if (lane == c) yb[c] = xc;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < kb; i += TTN_WG) {
+                double a = rhs[i];
+                for (int c = wb - 1; c >= 0; --c) a = fma(-K[(long long)(kb + c) * N + i], yb[c], a);
+                rhs[i] = a;
+            }
+            if (tid < wb) rhs[kb + tid] = yb[tid];
+            __syncthreads();
+        }
     }
     return 0;
 }
