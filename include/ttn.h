@@ -146,6 +146,17 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
  * must keep every two-site system n_i cap_i n_{i+1} cap_{i+2} <= 2048. */
 int ttn_mals_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t rmax);
 
+/* dmrg_linsolve(A, b, tt_start; N = 2, tol, sweep_schedule, rmax_schedule) (src/solvers/dmrg.jl:388-472): two-site sweeps
+ * (windows 1..d-2 forward with right_core_move!, d-1..2 backward with left_core_move!, dmrg.jl:187-232) walked through the
+ * reference's stage schedule — sweep s ends stage j when s == sweep_schedule[j], the sweep that would end the last stage is
+ * the closing solve at window 1 — with the ranks cut by cut_off_index (dmrg.jl:179-185) clamped to the stage's rmax.
+ * Every local system is assembled densely and solved by LU (the reference's `K_full` + `K \ Pb` branch, dmrg.jl:57-62,
+ * :173-175; its default KrylovKit branch solves the same system to linsolv_tol only).  sweep_schedule must be positive and
+ * strictly increasing (anything else does not terminate in the reference); at most 32 full sweeps per call.  Capacity and
+ * status as for ttn_mals_linsolve.  N = 1 is ttn_als_linsolve's territory and not offered here. */
+int ttn_dmrg_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t n_stages, const int64_t* sweep_schedule,
+                      const int64_t* rmax_schedule);
+
 /* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);
 

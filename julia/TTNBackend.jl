@@ -146,5 +146,10 @@ end
 #   ccall((:ttn_swap_sites, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Float64), q, length(swaps), swaps, threshold)
 # with swaps = _bubble_sort_swaps(perm) exactly as reorder computes it (src/qtt_tools.jl:759); ttn_compress_status reports a
 # rank that outgrew its slot (-5) or a Jacobi SVD that hit its sweep limit (-9).
+#
+# Two-site solvers on handles (INTEGRATION.md §2): x receives the result, its capacity bounds the adapted ranks,
+#   ccall((:ttn_mals_linsolve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64), A, b, x0, x, tol, rmax)
+#   ccall((:ttn_dmrg_linsolve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Int64}),
+#         A, b, x0, x, tol, length(sweep_schedule), sweep_schedule, rmax_schedule)      # dmrg_linsolve(...; N = 2), dmrg.jl:388
 
 end # module

@@ -922,6 +922,115 @@ def mals_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1
     return x
 
 
+def cut_off_index(s: np.ndarray, tol: float, degen_tol: float = 1.0e-10) -> int:
+    """cut_off_index(s, tol; degen_tol) (src/solvers/dmrg.jl:179-185): count(s > ||s|| tol), then extended over values
+    `isapprox` (rtol = atol = degen_tol) to the last kept one.  Known answer: test/test_dmrg.jl:20-25."""
+    s = np.asarray(s, dtype=np.float64)
+    k = int(np.sum(s > np.linalg.norm(s) * tol))
+    # Julia indexes s[k] here: k = 0 (all-zero spectrum) is a BoundsError in the reference; this restatement keeps k = 0
+    while 0 < k < len(s) and abs(s[k - 1] - s[k]) <= max(degen_tol, degen_tol * max(abs(s[k - 1]), abs(s[k]))):
+        k += 1
+    return k
+
+
+def dmrg_sweep_plan(sweep_schedule: Sequence[int], rmax_schedule: Sequence[int]):
+    """The (rmax of every full sweep, rmax of the closing step) the while-loop of dmrg_linsolve walks through
+    (src/solvers/dmrg.jl:421-443): sweep number s ends stage j when s == sweep_schedule[j]; the sweep that would end the last
+    stage is replaced by the closing solve at site 1."""
+    plan, n, j = [], 0, 0
+    while True:
+        n += 1
+        if n == sweep_schedule[j]:
+            j += 1
+            if j >= len(sweep_schedule):
+                return plan, int(rmax_schedule[-1])
+        plan.append(int(rmax_schedule[j]))
+
+
+def dmrg_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1.0e-12, sweep_schedule: Sequence[int] = (2,),
+                  rmax_schedule: Sequence[int] | None = None) -> TTvector:
+    """dmrg_linsolve(A, b, tt_start; N = 2, tol, sweep_schedule, rmax_schedule) (src/solvers/dmrg.jl:388-472) with every local
+    system solved densely (`K_full` + `K \\ Pb`, dmrg.jl:57-62, :173-175 — the branch the reference takes for
+    it_solver = false and small systems; its default KrylovKit branch solves the same system to linsolv_tol only).
+    Environments G (R, r, r) / H (R, r, r) (dmrg.jl:27-35), merged operator / right-hand-side cores Amid / b_mid (:38-47, :89-96),
+    core moves right_core_move! / left_core_move! (:187-232)."""
+    d = b.N
+    dims = tuple(tt_start.ttv_dims)
+    if rmax_schedule is None:
+        rmax_schedule = (math.isqrt(_prod(dims)),)
+    plan, rmax_final = dmrg_sweep_plan(list(sweep_schedule), list(rmax_schedule))
+    x = orthogonalize(tt_start)
+    Av, bv = A.tto_vec, b.ttv_vec
+    # window i (0-based) = sites i, i+1
+    Amid = [np.reshape(np.einsum("aIJx,ijxb->aIiJjb", np.transpose(Av[i], (2, 0, 1, 3)), Av[i + 1]),
+                       (A.tto_rks[i], dims[i] * dims[i + 1], dims[i] * dims[i + 1], A.tto_rks[i + 2]), order="F") for i in range(d - 1)]
+    bmid = [np.reshape(np.einsum("aix,jxb->aijb", np.transpose(bv[i], (1, 0, 2)), bv[i + 1]),
+                       (b.ttv_rks[i], dims[i] * dims[i + 1], b.ttv_rks[i + 2]), order="F") for i in range(d - 1)]
+    G = [None] * (d - 1)
+    Gb = [None] * (d - 1)
+    H = [None] * (d - 1)
+    Hb = [None] * (d - 1)
+    G[0] = np.ones((1, 1, 1))
+    Gb[0] = np.ones((1, 1))
+    H[d - 2] = np.ones((1, 1, 1))
+    Hb[d - 2] = np.ones((1, 1))
+
+    def upd_H(i):          # H[i-1], Hb[i-1] from site i+1 (dmrg.jl:27-30, :80-83)
+        xc = x.ttv_vec[i + 1]
+        H[i - 1] = np.einsum("jap,zpc,kbc,jkwz->wab", xc, H[i], xc, Av[i + 1], optimize=True)
+        Hb[i - 1] = np.einsum("pc,ibc,iap->ab", Hb[i], bv[i + 1], xc, optimize=True)
+
+    def upd_G(i):          # G[i+1], Gb[i+1] from site i (dmrg.jl:32-35, :85-88)
+        xc = x.ttv_vec[i]
+        G[i + 1] = np.einsum("jpa,zpc,kcb,jkzw->wab", xc, G[i], xc, Av[i], optimize=True)
+        Gb[i + 1] = np.einsum("pc,icb,ipa->ab", Gb[i], bv[i], xc, optimize=True)
+
+    for i in range(d - 2, 0, -1):
+        upd_H(i)
+
+    def ksolve(i):
+        Gi, Hi = G[i], H[i]
+        kd = (Gi.shape[1], Amid[i].shape[1], Hi.shape[1])
+        N = kd[0] * kd[1] * kd[2]
+        K = np.reshape(np.einsum("yad,zcf,ybez->abcdef", Gi, Hi, Amid[i], optimize=True), (N, N), order="F")
+        Pb = np.einsum("ap,piq,cq->aic", Gb[i], bmid[i], Hb[i], optimize=True)
+        Ku = np.triu(K) + np.triu(K, 1).T                              # Hermitian(K): the upper triangle
+        V = sla.solve(Ku, np.reshape(Pb, N, order="F"), assume_a="sym")
+        return np.reshape(V, kd, order="F")
+
+    def right_move(V, i, rmax):
+        rl, n1 = x.ttv_rks[i], dims[i]
+        u, sv, vt = sla.svd(np.reshape(V, (rl * n1, -1), order="F"), full_matrices=False, lapack_driver="gesdd")
+        r = min(cut_off_index(sv, tol), rmax)
+        x.ttv_rks[i + 1] = r
+        x.ttv_vec[i] = np.transpose(np.reshape(u[:, :r], (rl, n1, r), order="F"), (1, 0, 2)).copy()
+        x.ttv_ot[i] = 1
+        x.ttv_ot[i + 1] = 0
+        return np.reshape(sv[:r, None] * vt[:r, :], (r, -1, V.shape[2]), order="F")          # V_move
+
+    def left_move(V, i, rmax):       # the move at site j = i+1
+        n2, rr = dims[i + 1], x.ttv_rks[i + 2]
+        u, sv, vt = sla.svd(np.reshape(V, (-1, n2 * rr), order="F"), full_matrices=False, lapack_driver="gesdd")
+        r = min(cut_off_index(sv, tol), rmax)
+        x.ttv_rks[i + 1] = r
+        x.ttv_vec[i + 1] = np.transpose(np.reshape(vt[:r, :], (r, n2, rr), order="F"), (1, 0, 2)).copy()
+        x.ttv_ot[i + 1] = -1
+        x.ttv_ot[i] = 0
+        return np.reshape(u[:, :r] * sv[None, :r], (V.shape[0], -1, r), order="F")           # V_move
+
+    for rmax in plan:
+        for i in range(d - 2):                                        # first half sweep (:446-456)
+            right_move(ksolve(i), i, rmax)
+            upd_G(i)
+        for i in range(d - 2, 0, -1):                                 # second half sweep (:459-470)
+            left_move(ksolve(i), i, rmax)
+            upd_H(i)
+    Vm = left_move(ksolve(0), 0, rmax_final)                          # closing step (:426-441)
+    x.ttv_vec[0] = np.transpose(np.reshape(Vm, (1, dims[0], -1), order="F"), (1, 0, 2)).copy()
+    x.ttv_ot[0] = 0
+    return x
+
+
 # --------------------------------------------------------------------------------------
 # Explicit time steppers (callers of the hot path) — src/solvers/euler.jl:76-97, :193-209
 # --------------------------------------------------------------------------------------

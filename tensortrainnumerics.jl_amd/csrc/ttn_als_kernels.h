@@ -445,6 +445,7 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
 //   H_i  (R_{i+1}, n_{i+1}, r_{i+2}, n_{i+1}, r_{i+2})   couples sites i, i+1          (:10-40)
 //   Hb_i (rb_{i+1}, n_{i+1}, r_{i+2})                                                  (:60-92)
 // -------------------------------------------------------------------------------------------------
+#define TTN_DMRG_MAX_SWEEPS 32
 struct MalsArgs {
     AlsArgs L;                   // operator, handles, scratch offsets (off[2d..], off[3d..] = the MALS H / Hb slots)
     CompressArgs C;              // Jacobi knobs, status, sweep statistics for wg_hsvd_step (C.scratch unused)
@@ -452,6 +453,12 @@ struct MalsArgs {
     int rmax;
     long long offM2, offXg, offUs, offSig;     // SVD scratch
     int pmax, qmax;
+    // mode 0: mals_linsolve (one forward and one backward half sweep over all d-1 windows, rank rule sv_trunc).
+    // mode 1: dmrg_linsolve with N = 2 (src/solvers/dmrg.jl:421-472): `nsweeps` sweeps (windows 0..d-3 forward, d-2..1 backward,
+    //         sweep s capped at rmax_sweep[s]) and the closing solve at window 0 with a left move capped at rmax_final;
+    //         rank rule cut_off_index (dmrg.jl:179-185).
+    int mode, nsweeps, rmax_final;
+    int rmax_sweep[TTN_DMRG_MAX_SWEEPS];
 };
 
 __global__ void __launch_bounds__(TTN_WG) k_mals_linsolve(MalsArgs Q) {
@@ -583,27 +590,31 @@ __global__ void __launch_bounds__(TTN_WG) k_mals_linsolve(MalsArgs Q) {
     }
     for (int i = d - 2; i >= 1; --i) update_H(i);
     int status = 0;
-    for (int dir = 0; dir < 2 && !status; ++dir) {
-        for (int step = 0; step < d - 1 && !status; ++step) {
-            const int i = dir == 0 ? step : d - 2 - step;
-            int na, nb;
-            if (!ksolve(i, na, nb)) { status = 3; break; }
-            const int n2 = uni32(P.x.dims[i + 1]);
-            const int cap = min((int)P.x.cap[i + 1], Q.rmax);
-            double* xi = XC(i);
-            double* xn = XC(i + 1);
-            int r;
-            if (dir == 0)        // right_core_move_mals: x_i <- U, x_{i+1} <- S V'
-                r = wg_hsvd_step(Q.C, b, S, mkview(Pb, plain(1), plain(na)), na, nb, M2, 2, n2, 0, xi, xn, Q.tol, (int)P.x.cap[i + 1], lds, 1, Q.rmax);
-            else                 // left_core_move_mals: x_{i+1} <- V', x_i <- U S  (the step on the transposed view)
-                r = wg_hsvd_step(Q.C, b, S, mkview(Pb, plain(na), plain(1)), nb, na, M2, 1, n2, 0, xn, xi, Q.tol, (int)P.x.cap[i + 1], lds, 1, Q.rmax);
-            (void)cap;
-            if (r < 0) { status = 2; break; }
-            if (tid == 0) xr[i + 1] = r;
-            __syncthreads();
-            if (dir == 0) als_update_G(E, i);
-            else if (i > 0) update_H(i);
-        }
+    const int mode = uni32(Q.mode);
+    const int per = mode == 0 ? 2 * (d - 1) : 2 * (d - 2);                 // windows visited by one sweep
+    const int total = mode == 0 ? per : uni32(Q.nsweeps) * per + 1;
+    const int rule = mode == 0 ? 1 : 2;
+    for (int t = 0; t < total && !status; ++t) {
+        int i, dir, rmax;
+        if (mode == 0) { dir = t >= d - 1; i = dir ? 2 * (d - 1) - 1 - t : t; rmax = Q.rmax; }
+        else if (t == total - 1) { i = 0; dir = 1; rmax = Q.rmax_final; }
+        else { const int u = t % per; dir = u >= d - 2; i = dir ? 2 * (d - 2) - u : u; rmax = Q.rmax_sweep[t / per]; }
+        i = uni32(i); dir = uni32(dir); rmax = uni32(rmax);
+        int na, nb;
+        if (!ksolve(i, na, nb)) { status = 3; break; }
+        const int n2 = uni32(P.x.dims[i + 1]);
+        double* xi = XC(i);
+        double* xn = XC(i + 1);
+        int r;
+        if (dir == 0)        // right_core_move_mals / right_core_move!: x_i <- U, x_{i+1} <- S V'
+            r = wg_hsvd_step(Q.C, b, S, mkview(Pb, plain(1), plain(na)), na, nb, M2, 2, n2, 0, xi, xn, Q.tol, (int)P.x.cap[i + 1], lds, rule, rmax);
+        else                 // left_core_move_mals / left_core_move!: x_{i+1} <- V', x_i <- U S  (the step on the transposed view)
+            r = wg_hsvd_step(Q.C, b, S, mkview(Pb, plain(na), plain(1)), nb, na, M2, 1, n2, 0, xn, xi, Q.tol, (int)P.x.cap[i + 1], lds, rule, rmax);
+        if (r < 0) { status = 2; break; }
+        if (tid == 0) xr[i + 1] = r;
+        __syncthreads();
+        if (dir == 0) als_update_G(E, i);
+        else if (i > 0) update_H(i);
     }
     if (status && tid == 0) P.status[b] = status;
 }

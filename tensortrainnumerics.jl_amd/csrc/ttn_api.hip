@@ -1065,8 +1065,8 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
 }
 
 // ---- mals_linsolve -----------------------------------------------------------------------------------------------
-int ttn_mals_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t rmax) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+// the two-site solvers: mode 0 = mals_linsolve, mode 1 = dmrg_linsolve (N = 2) with `plan` = the rank cap of every full sweep
+static int two_site_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t rmax, int mode, const std::vector<int64_t>& plan) {
     NEED_INIT();
     if (!A || !b || !x0 || !x) return fail(TTN_ERR_ARG, "null handle");
     if (tol < 0.0 || rmax < 1) return fail(TTN_ERR_ARG, "bad tol / rmax");
@@ -1139,13 +1139,44 @@ int ttn_mals_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double t
     Q.tol = tol;
     Q.rmax = (int)std::min<int64_t>(rmax, 1 << 30);
     Q.pmax = (int)pmax; Q.qmax = (int)qmax;
+    Q.mode = mode;
+    Q.nsweeps = (int)plan.size();
+    Q.rmax_final = Q.rmax;
+    int64_t rtop = rmax;
+    for (size_t s_ = 0; s_ < plan.size(); ++s_) { Q.rmax_sweep[s_] = (int)std::min<int64_t>(plan[s_], 1 << 30); rtop = std::max(rtop, plan[s_]); }
     hipLaunchKernelGGL(k_mals_linsolve, dim3(batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, Q);
     HIPCHK(hipGetLastError());
-    for (int m = 1; m < d; ++m) x->bound[m] = std::min<int64_t>(x->cap[m], rmax);
+    for (int m = 1; m < d; ++m) x->bound[m] = std::min<int64_t>(x->cap[m], rtop);
     x->bound[0] = 1; x->bound[d] = 1;
     for (int bb = 0; bb < batch; ++bb)
-        for (int k = 0; k < d; ++k) x->ot[(size_t)bb * d + k] = (k == 0) ? 0 : 1;        // after the backward half sweep (mals.jl:116-117)
+        for (int k = 0; k < d; ++k)         // mals: after the backward half sweep (mals.jl:116-117); dmrg: left_core_move! (dmrg.jl:222-223, :440)
+            x->ot[(size_t)bb * d + k] = (k == 0) ? 0 : (mode == 0 ? 1 : -1);
     return TTN_OK;
+}
+
+int ttn_mals_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t rmax) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return two_site_linsolve(A, b, x0, x, tol, rmax, 0, {});
+}
+
+int ttn_dmrg_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t n_stages, const int64_t* sweep_schedule,
+                      const int64_t* rmax_schedule) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (n_stages < 1 || !sweep_schedule || !rmax_schedule) return fail(TTN_ERR_ARG, "dmrg_linsolve: empty schedule");
+    for (int64_t j = 0; j < n_stages; ++j) {
+        // the reference's while-loop (dmrg.jl:421-426) only terminates for positive, strictly increasing stage ends
+        if (sweep_schedule[j] < 1 || (j && sweep_schedule[j] <= sweep_schedule[j - 1])) return fail(TTN_ERR_ARG, "dmrg_linsolve: sweep_schedule must be positive and strictly increasing");
+        if (rmax_schedule[j] < 1) return fail(TTN_ERR_ARG, "dmrg_linsolve: bad rmax_schedule");
+    }
+    std::vector<int64_t> plan;
+    int64_t n = 0, j = 0;
+    for (;;) {
+        ++n;
+        if (n == sweep_schedule[j]) { if (++j >= n_stages) break; }
+        plan.push_back(rmax_schedule[j]);
+        if ((int64_t)plan.size() > TTN_DMRG_MAX_SWEEPS) return fail(TTN_ERR_UNSUPPORTED, "dmrg_linsolve: more than 32 sweeps in one call");
+    }
+    return two_site_linsolve(A, b, x0, x, tol, rmax_schedule[n_stages - 1], 1, plan);
 }
 
 // status of the last dense kernel (synchronises): returns TTN_ERR_NO_CONVERGENCE if any train failed

@@ -25,7 +25,8 @@ struct HsvdArgs {
 //   2 (right move): core = x_i (n1, r_l, r) <- U, contiguous; remainder S V' -> x_{i+1}[x, j, c] = (S V')[j, x + n c]   (n = n2)
 //   3 (left move, called on the TRANSPOSED view): core = x_{i+1}[x, j, c] <- V'[j, x + n c]; remainder (U S) -> x_i, contiguous
 // `rule` 0: r = count(s >= tol) (absolute); 1: sv_trunc (mals.jl:42-56: drop the tail while its weight stays below
-// tol * ||s||^2, keep the value that crossed the line) clamped to `rclamp`.
+// tol * ||s||^2, keep the value that crossed the line) clamped to `rclamp`; 2: cut_off_index (dmrg.jl:179-185: count(s > ||s|| tol),
+// extended over values within 1e-10 (relative and absolute) of the last kept one) clamped to `rclamp`.
 // Returns r (>= 1), or -1 if r exceeds `cap` (nothing written).
 __device__ __noinline__ int wg_hsvd_step(const CompressArgs& P, int b, const BondCtx& S, View Av, int a, int bcols, double* M2,
                                          int layout, int n, int rfix, double* core, double* rem, double tol, int cap, double* lds,
@@ -67,7 +68,17 @@ __device__ __noinline__ int wg_hsvd_step(const CompressArgs& P, int b, const Bon
     if (tid == 0) {
         int r = 0;
         if (rule == 0) { for (int i = 0; i < p; ++i) r += (S.sigs[i] * s0 >= tol) ? 1 : 0; }
-        else {
+        else if (rule == 2) {
+            double norm2 = 0.0;
+            for (int i = 0; i < p; ++i) { const double sv = S.sigs[i] * s0; norm2 = fma(sv, sv, norm2); }
+            const double thr = sqrt(norm2) * tol;
+            for (int i = 0; i < p; ++i) r += (S.sigs[i] * s0 > thr) ? 1 : 0;
+            while (r > 0 && r < p) {                    // isapprox(s[k], s[k+1]; rtol = atol = 1e-10)
+                const double u = S.sigs[r - 1] * s0, v = S.sigs[r] * s0;
+                if (fabs(u - v) <= fmax(1.0e-10, 1.0e-10 * fmax(fabs(u), fabs(v)))) ++r; else break;
+            }
+            if (r > rclamp) r = rclamp;
+        } else {
             r = p;
             if (tol != 0.0) {
                 double norm2 = 0.0, weight = 0.0;

@@ -15,6 +15,7 @@ solvers of the implicit steppers are not built.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import List, Sequence
 
@@ -448,6 +449,41 @@ def mals_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1
     db, dx0 = DeviceTT.from_host(b), DeviceTT.from_host(tt_start)
     dx = DeviceTT(tt_start.ttv_dims, mals_capacity(tt_start.ttv_dims, tt_start.ttv_rks, rmax))
     mals_linsolve_(dA, db, dx0, dx, tol, rmax)
+    D.compress_status(dx)
+    dx.max_ranks()
+    return dx.download(0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dmrg_linsolve, N = 2 (src/solvers/dmrg.jl:388-472) — the same persistent two-site kernel in its DMRG mode
+# ---------------------------------------------------------------------------------------------------------------------
+def dmrg_linsolve_(A: DeviceTTO, b: DeviceTT, x0: DeviceTT, x: DeviceTT, tol: float = 1.0e-12, sweep_schedule: Sequence[int] = (2,),
+                   rmax_schedule: Sequence[int] | None = None) -> DeviceTT:
+    """x_b = dmrg_linsolve(A, b_b, x0_b; N = 2, tol, sweep_schedule, rmax_schedule) for every train of the batch, local systems
+    solved densely (the reference's it_solver = false branch, dmrg.jl:173-175); x's capacity bounds the adapted ranks."""
+    if rmax_schedule is None:
+        rmax_schedule = (math.isqrt(math.prod(x0.dims)),)                   # dmrg.jl:391
+    ss = [int(v) for v in sweep_schedule]
+    rs = [int(min(v, 2 ** 30)) for v in rmax_schedule]
+    if len(rs) < len(ss):
+        raise _lib.TTNError("dmrg_linsolve: rmax_schedule is shorter than sweep_schedule")      # BoundsError in the reference
+    n = len(ss)
+    arr = (C.c_int64 * max(n, 1))
+    _lib.check(_lib.lib().ttn_dmrg_linsolve(A.h, b.h, x0.h, x.h, float(tol), n, arr(*ss) if n else None, arr(*rs[:n]) if n else None))
+    return x
+
+
+def dmrg_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1.0e-12, sweep_schedule: Sequence[int] = (2,),
+                  rmax_schedule: Sequence[int] | None = None, N: int = 2) -> TTvector:
+    """Host-level form for one right-hand side."""
+    if N != 2:
+        raise _lib.TTNError("dmrg_linsolve: only the two-site scheme N = 2 is offered (single-site: als_linsolve)")
+    if rmax_schedule is None:
+        rmax_schedule = (math.isqrt(math.prod(tt_start.ttv_dims)),)
+    dA = DeviceTTO(A)
+    db, dx0 = DeviceTT.from_host(b), DeviceTT.from_host(tt_start)
+    dx = DeviceTT(tt_start.ttv_dims, mals_capacity(tt_start.ttv_dims, tt_start.ttv_rks, max(int(v) for v in rmax_schedule)))
+    dmrg_linsolve_(dA, db, dx0, dx, tol, sweep_schedule, rmax_schedule)
     D.compress_status(dx)
     dx.max_ranks()
     return dx.download(0)

@@ -79,3 +79,19 @@ res = tt_norm_stable(O.sub(O.apply(A, gotm), b)) / tt_norm_stable(b)
 resc = tt_norm_stable(O.sub(O.apply(A, refm), b)) / tt_norm_stable(b)
 print(f"mals_linsolve (tol 1e-12, rmax {rmax}): ranks {gotm.ttv_rks} (cpu {refm.ttv_rks}); device {tm.ms:.1f} ms for {B} systems; cpu oracle {t_cpu * 1e3:.1f} ms each;"
       f" residual {res:.2e} (cpu {resc:.2e})")
+
+# dmrg_linsolve (N = 2) on the same problem: examples/Laplace_pde.jl:27 runs the default schedule; a longer one shows convergence
+for sched, rmaxs in (([2], [rmax]), ([6], [rmax])):
+    T.solvers.dmrg_linsolve_(dA, dbm, dx0m, dxm, 1e-10, sched, rmaxs)
+    T.device.compress_status(dxm)
+    with T.StreamTimer() as tm:
+        T.solvers.dmrg_linsolve_(dA, dbm, dx0m, dxm, 1e-10, sched, rmaxs)
+    T.device.compress_status(dxm)
+    t0 = time.time()
+    refd = O.dmrg_linsolve(A, b, x0m, tol=1e-10, sweep_schedule=sched, rmax_schedule=rmaxs)
+    t_cpu = time.time() - t0
+    gotd = to_oracle(dxm.download(0))
+    res = tt_norm_stable(O.sub(O.apply(A, gotd), b)) / tt_norm_stable(b)
+    resc = tt_norm_stable(O.sub(O.apply(A, refd), b)) / tt_norm_stable(b)
+    print(f"dmrg_linsolve (tol 1e-10, schedule {sched} / {rmaxs}): ranks {gotd.ttv_rks} (cpu {refd.ttv_rks}); device {tm.ms:.1f} ms for {B} systems;"
+          f" cpu oracle {t_cpu * 1e3:.1f} ms each; residual {res:.2e} (cpu {resc:.2e}); rel diff {tt_rel_diff(gotd, refd):.1e}")

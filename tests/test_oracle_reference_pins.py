@@ -420,3 +420,40 @@ def test_mals_linsolve_reference_assertions():
     A, b, x0 = spd(d, 2.0), O.rand_tt((2,) * d, 2, rng), O.rand_tt((2,) * d, 2, rng)
     dense = np.linalg.solve(O.qtto_to_matrix(A), O.qtt_to_vector(b))
     assert np.max(np.abs(O.qtt_to_vector(O.mals_linsolve(A, b, x0, tol=1e-14, rmax=64)) - dense)) <= 1e-11 * np.max(np.abs(dense))
+
+
+def test_dmrg_linsolve_reference_assertions():
+    """test/test_dmrg.jl:20-75: the cut_off_index known answer and the N = 2 dmrg_linsolve cases (NumPy inputs, dense local
+    solves), plus the sweep plan the reference's while-loop walks through and exactness against the dense solve."""
+    s = np.array([1.0, 1.0 - 5.0e-11, 0.1])
+    assert O.cut_off_index(s, (1.0 - 2.0e-11) / np.linalg.norm(s)) == 2          # test_dmrg.jl:20-25
+    assert O.cut_off_index(np.array([3.0, 2.0, 1e-3, 1e-9]), 1e-6) == 3
+    assert O.cut_off_index(np.array([1.0, 1e-11, 1e-12, 1e-13]), 1e-11 * 0.5) == 4   # the absolute 1e-10 window swallows the tail
+    assert O.dmrg_sweep_plan([2], [4]) == ([4], 4)                               # default schedule: one sweep + the closing step
+    assert O.dmrg_sweep_plan([2, 4], [2, 8]) == ([2, 8, 8], 8)
+    assert O.dmrg_sweep_plan([1], [3]) == ([], 3)
+    rng = np.random.default_rng(1234)
+
+    def spd(d, shift):
+        return O.tto_add(O.Delta(d), O.tto_scale(shift, O.id_tto(d)))
+
+    def resid(A, x, b):
+        return O.norm(O.sub(O.apply(A, x), b)) / max(O.norm(b), np.finfo(float).eps)
+
+    d = 4
+    b, x0 = O.rand_tt((2,) * d, [1, 2, 2, 2, 1], rng), O.rand_tt((2,) * d, [1, 2, 2, 2, 1], rng)
+    x = O.dmrg_linsolve(spd(d, 3.0), b, x0, sweep_schedule=[2], rmax_schedule=[4])
+    assert x.N == d and x.ttv_dims == (2,) * d and x.ttv_ot == [0, -1, -1, -1]
+    assert resid(spd(d, 10.0), O.dmrg_linsolve(spd(d, 10.0), b, x0, sweep_schedule=[4], rmax_schedule=[8]), b) < 0.5
+    x1 = O.rand_tt((2,) * d, [1] * 5, rng)
+    x = O.dmrg_linsolve(spd(d, 5.0), b, x1, sweep_schedule=[2, 4], rmax_schedule=[2, 8])
+    assert x.ttv_dims == b.ttv_dims
+    b1 = O.rand_tt((2,) * d, [1] * 5, rng)
+    assert resid(O.id_tto(d), O.dmrg_linsolve(O.id_tto(d), b1, x1, sweep_schedule=[4], rmax_schedule=[4]), b1) < 0.05
+    d = 6
+    A, b, x0 = spd(d, 2.0), O.rand_tt((2,) * d, 2, rng), O.rand_tt((2,) * d, 2, rng)
+    dense = np.linalg.solve(O.qtto_to_matrix(A), O.qtt_to_vector(b))
+    assert np.max(np.abs(O.qtt_to_vector(O.dmrg_linsolve(A, b, x0, tol=1e-14, sweep_schedule=[3], rmax_schedule=[64])) - dense)) <= 1e-11 * np.max(np.abs(dense))
+    # the two-site schemes agree where both converge: mals after its sweep, dmrg after one sweep + closing step
+    xm = O.mals_linsolve(A, b, x0, tol=1e-14, rmax=64)
+    assert np.max(np.abs(O.qtt_to_vector(xm) - dense)) <= 1e-11 * np.max(np.abs(dense))
