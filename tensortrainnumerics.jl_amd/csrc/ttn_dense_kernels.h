@@ -1580,6 +1580,7 @@ struct CompressArgs {
 #define COMPRESS_LDS_X_DOUBLES (128 * 128)
 #define COMPRESS_LDS_BYTES ((GEMM_LDS_TOTAL + 32 + 2 * QR_NB * QR_NB + QR_NB + 8 + 8 + 128) * sizeof(double))
 #define FAST_KAPPA_MAX 128.0          // fast paths are used only when sigma_max/sigma_min <= this (error ~ eps*kappa^2)
+#define FAST_DIAG_TOL 2.0e-12         // route F: A'^T A' counts as diagonal below this (relative to sqrt(G_ii G_jj))
 #define FAST_CHECK_TOL 2.0e-11        // a-posteriori bound on |Rf Rf^T - Sigma| (and Lf^T Lf - Sigma), relative
 
 struct BondCtx {
@@ -1849,11 +1850,40 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         const View Gbv = mkview(S.Gb, plain(1), plain(128));
         const View Ccv = mkview(S.Cc, plain(1), plain(128));
         const View Xlv = mkview(S.ldsX, plain(1), plain(128));
+        bool diagA = false;
         if (ok) {
             wg_gemm(rm, rm, p, tview(Ap), Ap, Gav, 1.0 / (sA * sA), 0.0, lds);          // A'^T A'
             wg_gemm(rm, rm, q, Bp, tview(Bp), Gbv, 1.0 / (sB * sB), 0.0, lds);          // B' B'^T
             PROF_MARK(8)
-            if (rm <= 64) {
+            // A' = U D^(1/2) with orthonormal U (the left core of a bond step is left as U sqrt(S) by the step before it, so every
+            // R->L step of a sweep that follows an L->R sweep sees this): then M = U (D^(1/2) B') and the SVD of M is U times the SVD
+            // of the rm x q matrix N = D^(1/2) B' — no Cholesky factors, no core matrix, two output GEMMs instead of five.
+            // Detected, not assumed: |G_ij| <= FAST_DIAG_TOL sqrt(G_ii G_jj) for every off-diagonal entry of A'^T A'.
+            if (rm == 64 && !(P.fast & 4) && !(P.fast & 8)) {
+                double w = 0.0;
+                for (int e = tid; e < 64 * 64; e += TTN_WG) {
+                    const int i = e & 63, j = e >> 6;
+                    const double dii = S.Ga[i * 129], djj = S.Ga[j * 129];
+                    const double v = (dii > 0.0 && djj > 0.0) ? fabs(S.Ga[i + 128 * j]) / sqrt(dii * djj) : 1.0;
+                    if (i != j) w = fmax(w, v);
+                }
+                const double wmax = unif64(wg_max(w, S.red));
+                diagA = wmax <= FAST_DIAG_TOL;
+                if (P.prof && tid == 0) {            // diagnostics: largest off-diagonal level seen (1e-18 units), steps tested / taken
+                    long long* pf = P.prof + (long long)b * 16;
+                    const long long wl = (long long)fmin(wmax * 1e18, 9e18);
+                    if (wl > pf[12]) pf[12] = wl;
+                    pf[13] += 1; pf[14] += diagA ? 1 : 0;
+                }
+            }
+            if (diagA) {
+                // Gram matrix of N: D^(1/2) (B' B'^T) D^(1/2) -> T3
+                for (int e = tid; e < 64 * 64; e += TTN_WG) {
+                    const int i = e & 63, j = e >> 6;
+                    S.T3[i + 128 * j] = sqrt(S.Ga[i * 129]) * S.Gb[i + 128 * j] * sqrt(S.Ga[j * 129]);
+                }
+                __syncthreads();
+            } else if (rm <= 64) {
                 // both Cholesky factorisations at once, one per half of the workgroup (wg_chol2_lds128)
                 for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) { S.ldsX[e] = S.Ga[e]; S.ldsX[64 * 128 + e] = S.Gb[e]; }
                 __syncthreads();
@@ -1879,9 +1909,15 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         int r = 0, rk = 0;
         if (ok) {
             PROF_MARK(9)
+            int nsw = 1;
+            if (diagA) {
+                ok = wg_eig64(S.T3, 128, S.T2, 64, 64, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64) == 0;
+                for (int j = tid; j < 64; j += TTN_WG) S.perm[j] = j;
+                if (tid == 0) S.scal[0] = P.jneg_mult * P.jneg_mult * 64.0 * DBL_EPSILON * DBL_EPSILON * S.sigs[0] * S.sigs[0];
+                __syncthreads();
+            } else {
             // core C = L_A^T L_B  (rm x rm)
             wg_gemm(rm, rm, rm, tview(Gav), Gbv, Ccv, 1.0, 0.0, lds);
-            int nsw = 1;
             if (rm == 64 && !(P.fast & 4)) {
                 // the 64 x 64 core through the symmetric eigensolver: C C' = U S^2 U' gives the same image x_j = sigma_j u_j the
                 // Jacobi on the columns of C leaves (ttn_eig_kernels.h; the a-posteriori check below covers the squared condition)
@@ -1896,6 +1932,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 nsw = uni32(wg_svd_cols(P, S, rm, S.ldsX, 128, true));
                 nsw_total += (nsw < 0 ? -nsw : nsw);
             }
+            }
             ok = ok && (nsw > 0) && (S.sigs[rm - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[rm - 1] * S.sigs[rm - 1] > S.scal[0]);
             PROF_MARK(10)
         }
@@ -1908,8 +1945,16 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 const int row = e % rm, j = e / rm;
                 const double sj = S.sigs[j], xv = S.ldsX[S.perm[j] * 128 + row];
                 const double rs = sqrt(sj);
+                if (diagA) {
+                    // x_j = sigma_j w_j (w_j: left singular vector of N).  Lf = A' (D^(-1/2) w_j sqrt(s0 sigma_j) / sA),
+                    // Rf = (D^(1/2) w_j sqrt(s0) / (sB sqrt(sigma_j)))^T B'
+                    const double sd = sqrt(S.Ga[row * 129]);
+                    S.T1[j * 128 + row] = xv * (fa / (sd * rs));
+                    S.T2[j * 128 + row] = xv * sd * (fb / (sj * rs));
+                } else {
                 S.T1[j * 128 + row] = xv * (fa / (sj * sj * rs));
                 S.T2[j * 128 + row] = xv * (fb / (sj * rs));
+                }
             }
             __syncthreads();
             const View T1v = mkview(S.T1, plain(1), plain(128));
@@ -1918,6 +1963,10 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             double* RfT = S.M + (long long)p * rk;                          // rk x q, row-major (ld = q)
             const View Lft = mkview(LfT, plain(1), plain(p));
             const View Rft = mkview(RfT, plain(q), plain(1));
+            if (diagA) {
+                wg_gemm(p, rk, rm, Ap, T1v, Lft, 1.0, 0.0, lds);
+                wg_gemm(rk, q, rm, tview(T2v), Bp, Rft, 1.0, 0.0, lds);
+            } else {
             // Lf = A' * (L_B * (C^T * X_s))     (ldsX is free again: use it as the second temporary)
             wg_gemm(rm, rk, rm, tview(Ccv), T1v, mkview(S.T3, plain(1), plain(128)), 1.0, 0.0, lds);
             wg_gemm(rm, rk, rm, Gbv, mkview(S.T3, plain(1), plain(128)), T1v, 1.0, 0.0, lds);
@@ -1925,6 +1974,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             // Rf = (L_A * X_t)^T * B'
             wg_gemm(rm, rk, rm, Gav, T2v, mkview(S.T3, plain(1), plain(128)), 1.0, 0.0, lds);
             wg_gemm(rk, q, rm, tview(mkview(S.T3, plain(1), plain(128))), Bp, Rft, 1.0, 0.0, lds);
+            }
             // a-posteriori check: Lf^T Lf = Sigma, Rf Rf^T = Sigma
             wg_gemm(rk, rk, p, tview(Lft), Lft, mkview(S.T1, plain(1), plain(128)), 1.0, 0.0, lds);
             wg_gemm(rk, rk, q, Rft, tview(Rft), mkview(S.T2, plain(1), plain(128)), 1.0, 0.0, lds);
@@ -1952,7 +2002,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 if (tid == 0) *io.rank_out = r;
                 __syncthreads();
                 done = true;
-                route = 0;
+                route = diagA ? 3 : 0;
             }
         }
         PROF_MARK(6)

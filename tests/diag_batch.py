@@ -34,4 +34,7 @@ if os.environ.get("TTN_PROF"):
     print("phase ticks (100MHz):", {n: int(v) for n, v in zip(names, out)}, "total ms", tot / 1e5)
     st = (C.c_int64 * 120)()
     T._lib.check(T._lib.lib().ttn_prof_steps(0, st))
-    print("per step (route p:sweeps@kclk):", " ".join(f"{'FGH'[(v >> 48) & 3]}{(v >> 32) & 0xffff}:{v & 0xfff}@{(v >> 12) & 0xfffff}" for v in st[:2 * (d - 1)]))
+    print("per step (route p:sweeps@kclk):", " ".join(f"{'FGHD'[(v >> 48) & 3]}{(v >> 32) & 0xffff}:{v & 0xfff}@{(v >> 12) & 0xfffff}" for v in st[:2 * (d - 1)]))
+    for tb in range(min(B, 8)):
+        T._lib.check(T._lib.lib().ttn_prof_get(tb, out))
+        print(f"train {tb}: route-F steps tested for a diagonal left Gram {out[13]}, taken {out[14]}, largest off-diagonal level {out[12] * 1e-18:.2e}")

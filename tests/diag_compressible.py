@@ -30,4 +30,4 @@ if os.environ.get("TTN_PROF"):
     import ctypes as C
     st = (C.c_int64 * 120)()
     T._lib.check(T._lib.lib().ttn_prof_steps(0, st))
-    print("per step:", " ".join(f"{'FGH'[(v >> 48) & 3]}{(v >> 32) & 0xffff}:{v & 0xffffffff}" for v in st[:2 * (d - 1)]))
+    print("per step:", " ".join(f"{'FGHD'[(v >> 48) & 3]}{(v >> 32) & 0xffff}:{v & 0xffffffff}" for v in st[:2 * (d - 1)]))

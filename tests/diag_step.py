@@ -28,4 +28,4 @@ for k in sorted(ks):
     st = (C.c_int64 * 120)()
     T._lib.check(L.ttn_prof_steps(0, st))
     v = st[0]
-    print(f"bond {k}: {'FGH'[(v >> 48) & 3]}{(v >> 32) & 0xffff}:{v & 0xfff}@{(v >> 12) & 0xfffff} kclk ", {n: int(t) // 1000 for n, t in zip(names, out) if t})
+    print(f"bond {k}: {'FGHD'[(v >> 48) & 3]}{(v >> 32) & 0xffff}:{v & 0xfff}@{(v >> 12) & 0xfffff} kclk ", {n: int(t) // 1000 for n, t in zip(names, out) if t})
