@@ -1580,6 +1580,7 @@ struct CompressArgs {
 #define COMPRESS_LDS_X_DOUBLES (128 * 128)
 #define COMPRESS_LDS_BYTES ((GEMM_LDS_TOTAL + 32 + 2 * QR_NB * QR_NB + QR_NB + 8 + 8 + 128) * sizeof(double))
 #define FAST_KAPPA_MAX 128.0          // fast paths are used only when sigma_max/sigma_min <= this (error ~ eps*kappa^2)
+#define FAST_KAPPA_POLISH 32768.0     // Gram route with a Jacobi polish of U^T M up to this conditioning of the kept block
 #define FAST_DIAG_TOL 2.0e-12         // route F: A'^T A' counts as diagonal below this (relative to sqrt(G_ii G_jj))
 #define FAST_CHECK_TOL 2.0e-11        // a-posteriori bound on |Rf Rf^T - Sigma| (and Lf^T Lf - Sigma), relative
 
@@ -1594,14 +1595,16 @@ struct BondCtx {
 
 // Jacobi on the pj columns (length pj) of X, then singular values sigma_c = ||x_c|| sorted descending with a
 // stable order: perm[pos] = column, sigs[pos] = sigma (scaled units).  Returns the sweep count (<0: limit hit).
-__device__ int wg_svd_cols(const CompressArgs& P, const BondCtx& S, int pj, double* X, int ldx, bool in_lds) {
+__device__ int wg_svd_cols(const CompressArgs& P, const BondCtx& S, int pj, double* X, int ldx, bool in_lds, int mlen = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
-    const int nsw = in_lds ? wg_jacobi_lds128(pj, pj, X, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
+    // mlen: column length if it is not pj (LDS image only: the polish step of the Gram route runs r columns of length q)
+    const int nsw = (in_lds && mlen) ? wg_jacobi_lds128(mlen, pj, X, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
+                  : in_lds ? wg_jacobi_lds128(pj, pj, X, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
                   : (pj <= 256) ? wg_jacobi_blocked256(pj, pj, X, ldx, S.ldsX, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
                                 : wg_jacobi_cols(pj, pj, X, ldx, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal);
     for (int c = wave; c < pj; c += nwaves) {
         double a = 0.0;
-        for (int r = lane; r < pj; r += 64) { const double v = X[(long long)c * ldx + r]; a = fma(v, v, a); }
+        for (int r = lane; r < (mlen ? mlen : pj); r += 64) { const double v = X[(long long)c * ldx + r]; a = fma(v, v, a); }
         a = wave_sum(a);
         if (lane == 0) S.sig[c] = sqrt(a);
     }
@@ -2045,7 +2048,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         // small merged matrices (the rank-ramp steps) fit the LDS whole: their Householder LQ needs no GEMM calls and costs
         // about what the Gram + Cholesky do, without the conditioning gamble — route H directly
         const bool lq_in_lds = (long long)p * q <= GEMM_LDS_DOUBLES || GEMM_LDS_DOUBLES / p >= 2 * p;     // whole, or TSQR chunks (wg_lq_blocked)
-        const bool eig_ok = SWAP == 0 && P.fast && !(P.fast & 2) && need_lq && ((p == 128 && P.max_bond <= 64) || (p == 64 && P.max_bond < 64));
+        const bool eig_ok = SWAP == 0 && P.fast && !(P.fast & 2) && need_lq && ((p > 64 && p <= 128 && P.max_bond <= 64) || (p == 64 && P.max_bond < 64));
         for (int attempt = (SWAP == 0 && P.fast && need_lq && x_in_lds && p >= 2 && (!lq_in_lds || eig_ok)) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
             bool ok = true;
             bool use_eig = false;
@@ -2058,6 +2061,11 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 // Cholesky + Jacobi on L; same outputs (sigs, perm, X = sigma_j u_j in LDS), same a-posteriori check below
                 use_eig = eig_ok;
                 if (use_eig) {
+                    if (p > 64 && p < 128) {             // 64 < p < 128: the Gram matrix zero-padded to the 128-row solver (the padding adds
+                        for (int e = tid; e < 128 * 128; e += TTN_WG)      // exact zero eigenvalues below the wanted ones)
+                            if ((e & 127) >= p || (e >> 7) >= p) S.Ga[e] = 0.0;
+                        __syncthreads();
+                    }
                     const int r0 = (int)P.max_bond;
                     const int nev = (P.truncerr > 0.0 || (P.sv_out && step < P.sv_steps)) ? p : r0;
                     ok = ((p == 64) ? wg_eig64(S.Ga, 128, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64)
@@ -2141,7 +2149,54 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 // Gram route: the KEPT block must be well conditioned (error ~ eps*kappa^2, verified below); the discarded
                 // singular values only matter to the rank rule, i.e. when truncerr > 0 (then all of them must qualify).
                 const int rl = (P.truncerr > 0.0) ? p : r;
-                if (!((S.sigs[rl - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[rl - 1] * S.sigs[rl - 1] > S.scal[0]))) continue;
+                if (__builtin_expect(!((S.sigs[rl - 1] * FAST_KAPPA_MAX >= S.sigs[0]) && (S.sigs[rl - 1] * S.sigs[rl - 1] > S.scal[0])), 0)) {
+                    // Moderately ill-conditioned kept block and everything kept fits the LDS image: POLISH instead of starting over.
+                    // The eigenvectors U of the Gram matrix span the dominant subspace up to an angle theta ~ eps kappa^2 / relgap; the
+                    // r x q matrix B = U^T M is then nearly row-orthogonal, and a one-sided Jacobi on its rows (2-3 sweeps) delivers the
+                    // singular values and right vectors of M restricted to that subspace to Jacobi accuracy; the left vectors follow as
+                    // M v / sigma — one step of subspace iteration, so the product of the two outputs is M projected on the computed
+                    // right vectors and the singular values are off by theta^2 / 2 only (<= 5e-11 at FAST_KAPPA_POLISH).
+                    const bool polish = use_eig && SWAP == 0 && !(P.fast & 16) && P.truncerr == 0.0 && q <= 128 && r <= 64 && r >= 2 &&
+                                        (S.sigs[r - 1] * FAST_KAPPA_POLISH >= S.sigs[0]) && (S.sigs[r - 1] * S.sigs[r - 1] > S.scal[0]);
+                    if (!polish) continue;
+                    const double aneg0 = S.scal[0];
+                    for (int e = tid; e < p * r; e += TTN_WG) {
+                        const int row = e % p, j = e / p;
+                        const double sj = S.sigs[j], xv = X[(long long)S.perm[j] * ldx + row];
+                        S.Us[(long long)j * p + row] = ((sj > 0.0) && (sj * sj > aneg0)) ? xv / sj : 0.0;
+                    }
+                    __syncthreads();
+                    wg_gemm(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, mkview(S.M2, plain(q), plain(1)), inv_s0, 0.0, lds);
+                    for (int e = tid; e < r * 128; e += TTN_WG) { const int c = e & 127, j = e >> 7; S.ldsX[e] = (c < q) ? S.M2[(long long)j * q + c] : 0.0; }
+                    __syncthreads();
+                    const int nsp = uni32(wg_svd_cols(P, S, r, S.ldsX, 128, true, q));
+                    nsw_total += (nsp < 0 ? -nsp : nsp);
+                    if (nsp <= 0) continue;                                     // not converged: Householder route (M is intact)
+                    const View Rfv = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * r});
+                    const View Lo = wide ? Lfv : tview(Rfv);       // p x r
+                    const View Ro = wide ? Rfv : tview(Lfv);       // r x q
+                    const double sq0 = sqrt(s0), aneg = S.scal[0];
+                    for (int e = tid; e < r * q; e += TTN_WG) {
+                        const int col = e % q, j = e / q;
+                        const double sj = S.sigs[j], xv = S.ldsX[S.perm[j] * 128 + col];
+                        const bool keep = (sj > 0.0) && (sj * sj > aneg);
+                        Ro.p[ix(Ro.r, j) + ix(Ro.c, col)] = keep ? xv * (sq0 / sqrt(sj)) : 0.0;          // sqrt(s0 sigma_j) v_j
+                        S.M2[(long long)j * q + col] = keep ? xv * (sq0 / (sj * sqrt(sj))) : 0.0;
+                    }
+                    __syncthreads();
+                    wg_gemm(p, r, q, Mv, mkview(S.M2, plain(1), plain(q)), Lo, inv_s0, 0.0, lds);          // M v_j sqrt(s0) / (s0 sqrt(sigma_j))
+                    if (P.sv_out && step < P.sv_steps) {
+                        double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
+                        for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? S.sigs[i] * s0 : -1.0;
+                    }
+                    if (P.prof && tid == 0) P.prof[(long long)b * 16 + 15] += 1;
+                    if (tid == 0) *io.rank_out = r;
+                    __syncthreads();
+                    done = true;
+                    route = 1;
+                    PROF_MARK(5)
+                    continue;
+                }
             }
             if (attempt == 2 && P.sv_out && step < P.sv_steps) {
                 double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;

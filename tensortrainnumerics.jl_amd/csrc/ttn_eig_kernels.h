@@ -385,9 +385,9 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
     wg_tridiag<N>(Gg, ldg, Vst, lds);
     EIG_MARK(3)
     wg_bisect<N, 8>(nev, lds);
-    // eigenvalues out; all wanted ones must be positive
+    // eigenvalues out; those whose vectors are wanted must be positive (the others are only reported: 0 if not positive)
     int bad = 0;
-    for (int j = tid; j < nev; j += TTN_WG) { const double l = lam[j]; sig[j] = (l > 0.0) ? sqrt(l) : 0.0; bad |= !(l > 0.0); }
+    for (int j = tid; j < nev; j += TTN_WG) { const double l = lam[j]; sig[j] = (l > 0.0) ? sqrt(l) : 0.0; bad |= (j < r) && !(l > 0.0); }
     if (__syncthreads_or(bad)) return 1;
     EIG_MARK(4)
     wg_twisted<N>(r, lds, iwork, (lds_f64*)dwork);

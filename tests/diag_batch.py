@@ -37,4 +37,26 @@ if os.environ.get("TTN_PROF"):
     print("per step (route p:sweeps@kclk):", " ".join(f"{'FGHD'[(v >> 48) & 3]}{(v >> 32) & 0xffff}:{v & 0xfff}@{(v >> 12) & 0xfffff}" for v in st[:2 * (d - 1)]))
     for tb in range(min(B, 8)):
         T._lib.check(T._lib.lib().ttn_prof_get(tb, out))
-        print(f"train {tb}: route-F steps tested for a diagonal left Gram {out[13]}, taken {out[14]}, largest off-diagonal level {out[12] * 1e-18:.2e}")
+        print(f"train {tb}: route-F steps tested for a diagonal left Gram {out[13]}, taken {out[14]}, largest off-diagonal level {out[12] * 1e-18:.2e}; Gram steps finished by the Jacobi polish {out[15]}")
+    if os.environ.get("TTN_STEP"):
+        k = int(os.environ["TTN_STEP"])
+        rows = []
+        for tb in range(min(B, 64)):
+            T._lib.check(T._lib.lib().ttn_prof_steps(tb, st))
+            v = st[k]
+            tot = sum(((w >> 12) & 0xfffff) for w in st[:2 * (d - 1)])
+            rows.append(f"{'FGHD'[(v >> 48) & 3]}{(v >> 32) & 0xffff}@{(v >> 12) & 0xfffff}/{tot}")
+        print(f"step {k} per train (route p@kclk/total kclk):", " ".join(rows))
+    if os.environ.get("TTN_OUTLIERS"):
+        tots = []
+        for tb in range(B):
+            T._lib.check(T._lib.lib().ttn_prof_steps(tb, st))
+            steps = list(st[:2 * (d - 1)])
+            tots.append((sum(((w >> 12) & 0xfffff) for w in steps), tb, steps))
+        tots.sort()
+        print("per-train total kclk: min", tots[0][0], "median", tots[len(tots) // 2][0], "max", tots[-1][0])
+        med = tots[len(tots) // 2][2]
+        for tot, tb, steps in tots[-4:]:
+            diff = [f"{k}:{'FGHD'[(v >> 48) & 3]}{(v >> 32) & 0xffff}@{(v >> 12) & 0xfffff}(median {(m >> 12) & 0xfffff})" for k, (v, m) in enumerate(zip(steps, med))
+                    if abs(((v >> 12) & 0xfffff) - ((m >> 12) & 0xfffff)) > 150]
+            print(f"train {tb}: total {tot}: " + " ".join(diff))

@@ -432,6 +432,31 @@ def test_headline_config_properties(T):
     assert tt_rel_diff(to_oracle(again), to_oracle(got)) <= 1e-10
 
 
+@pytest.mark.parametrize("seed", [30, 192, 210])
+def test_headline_config_singular_values(T, seed):
+    """C3 through the fused op with every bond step's singular values captured.  The 96-row step at the right end of the L->R
+    half (128 x 96, 64 kept) has a kept-block conditioning of 1.4e2 / 2.4e3 / 5e3 for these seeds: it takes the zero-padded
+    Gram + eigensolver route finished by the Jacobi polish of U^T M; the R->L half takes the
+    diagonal-left form of route F.  Same bar as everywhere: ranks exact, kept singular values rtol 1e-10 (atol 1e-13 sigma_1,
+    which is where LAPACK's own accuracy for the small values of the ill-conditioned ramp steps ends), tensor 1e-9."""
+    d, r = 30, 64
+    x = T.rand_tt((2,) * d, r, seed=seed)
+    A = T.Delta(d)
+    dA, dx = T.DeviceTTO(A), T.DeviceTT.from_host(x)
+    dy = T.DeviceTT(x.ttv_dims, [a * b for a, b in zip(A.tto_rks, x.ttv_rks)])
+    dy.capture_singular_values(True)
+    T.device.apply_compress(dA, dx, dy, r, 0.0, 1)
+    T.device.compress_status(dy)
+    sv = []
+    ref = O.tt_compress_(O.apply(O.Delta(d), to_oracle(x)), r, svals_out=sv)
+    got = dy.download()
+    assert got.ttv_rks == ref.ttv_rks
+    for i, s_ref in enumerate(sv):
+        s = dy.singular_values(0, i)
+        assert np.allclose(s[: len(s_ref)], s_ref, rtol=1e-10, atol=1e-13 * s_ref[0]), f"bond step {i}"
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
+
+
 # ------------------------------------------------------------------------------------------------
 # edge cases: general physical dimensions, short sides > 128 (global-memory Jacobi fallback), truncerr > 0 on
 # incompressible input, several sweeps, single bonds, ragged batches
