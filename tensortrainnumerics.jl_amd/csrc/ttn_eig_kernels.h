@@ -384,7 +384,11 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
     EIG_MARK(2)
     wg_tridiag<N>(Gg, ldg, Vst, lds);
     EIG_MARK(3)
-    wg_bisect<N, 8>(nev, lds);
+    // lanes per eigenvalue: the Sturm loop is issue bound, so the optimum is ONE busy wave per SIMD (4 waves) — 4 lanes for the
+    // 33..64 eigenvalues of the headline steps (23 rounds of 5-section), 8 lanes for up to 32 (17 rounds of 9-section); more
+    // eigenvalues than that (nev = N with truncerr > 0) simply occupy more waves
+    if (nev <= 32) wg_bisect<N, 8>(nev, lds);
+    else wg_bisect<N, 4>(nev, lds);
     // eigenvalues out; those whose vectors are wanted must be positive (the others are only reported: 0 if not positive)
     int bad = 0;
     for (int j = tid; j < nev; j += TTN_WG) { const double l = lam[j]; sig[j] = (l > 0.0) ? sqrt(l) : 0.0; bad |= (j < r) && !(l > 0.0); }
