@@ -1567,7 +1567,9 @@ struct CompressArgs {
     double jtol_mult;      // Jacobi convergence threshold = jtol_mult * sqrt(m) * eps
     long long* prof;       // null, or cycle counters per phase (TTN_PROF=1 diagnostic launches only)
     double jneg_mult;      // columns below jneg_mult * sqrt(m) * eps * max column norm are treated as zero
-    int fast;              // 1: try the Gram/Cholesky fast paths (verified a posteriori) before Householder
+    int fast;              // 0: Householder route only; odd: try the Gram / factored fast paths (verified a posteriori) first.
+                           // Diagnostic bits (TTN_FAST): 2 no eigensolver in route G (Cholesky + Jacobi), 4 none in route F,
+                           // 8 no diagonal-left shortcut in route F, 16 no Jacobi polish after a failed conditioning test
     // fused apply (ttn_apply_compress): psi = A * x is never materialised.  During the FIRST L->R sweep core k+1 of psi
     // is still virtual (= A_{k+1} applied to x_{k+1}); psi's ranks already hold A.rks .* x.rks.
     int fused;

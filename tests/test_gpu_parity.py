@@ -567,6 +567,30 @@ def test_fast_routes_agree_with_robust_route(T, monkeypatch):
     assert tt_rel_diff(to_oracle(fast), to_oracle(robust)) <= 1e-10
 
 
+@pytest.mark.parametrize("seed", [3, 192])
+def test_rank64_route_variants_agree(T, monkeypatch, seed):
+    """The rank-64 sweep (128-row Gram steps, the zero-padded 96-row Gram step with or without its Jacobi polish, the
+    diagonal-left form of route F) against the same sweep with each shortcut switched off through the diagnostic bits of
+    TTN_FAST (csrc/ttn_dense_kernels.h, CompressArgs.fast) and against the all-Householder route: same ranks, tensors to 1e-10."""
+    d, r = 16, 64
+    A = T.Delta(d)
+    x = T.rand_tt((2,) * d, r, seed=seed)
+    dA, dx = T.DeviceTTO(A), T.DeviceTT.from_host(x)
+
+    def run():
+        dy = T.DeviceTT(x.ttv_dims, [a * b for a, b in zip(A.tto_rks, x.ttv_rks)])
+        T.device.apply_compress(dA, dx, dy, r, 0.0, 1)
+        T.device.compress_status(dy)
+        return dy.download()
+
+    base = run()
+    for bits in ("9", "17", "25", "31", "0"):          # 1|8, 1|16, 1|8|16, every eigensolver shortcut off, Householder only
+        monkeypatch.setenv("TTN_FAST", bits)
+        other = run()
+        assert other.ttv_rks == base.ttv_rks, bits
+        assert tt_rel_diff(to_oracle(other), to_oracle(base)) <= 1e-10, bits
+
+
 @pytest.mark.parametrize("dims,oprks,xr,mb", [((2,) * 30, None, 64, 64), ((2, 3, 2, 2, 3, 2, 2), [1, 2, 3, 2, 4, 2, 3, 1], 5, 6),
                                               ((4, 2, 3, 4, 2), [1, 3, 2, 2, 3, 1], 7, 9)])
 def test_fused_apply_compress_equals_apply_then_compress(T, monkeypatch, dims, oprks, xr, mb):
