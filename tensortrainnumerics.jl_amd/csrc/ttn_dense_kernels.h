@@ -1569,7 +1569,8 @@ struct CompressArgs {
     double jneg_mult;      // columns below jneg_mult * sqrt(m) * eps * max column norm are treated as zero
     int fast;              // 0: Householder route only; odd: try the Gram / factored fast paths (verified a posteriori) first.
                            // Diagnostic bits (TTN_FAST): 2 no eigensolver in route G (Cholesky + Jacobi), 4 none in route F,
-                           // 8 no diagonal-left shortcut in route F, 16 no Jacobi polish after a failed conditioning test
+                           // 8 no diagonal-left shortcut in route F, 16 no Jacobi polish after a failed conditioning test,
+                           // 64 Gram / reflector / check matrices in their own scratch instead of the dead T buffer
     // fused apply (ttn_apply_compress): psi = A * x is never materialised.  During the FIRST L->R sweep core k+1 of psi
     // is still virtual (= A_{k+1} applied to x_{k+1}); psi's ranks already hold A.rks .* x.rks.
     int fused;
@@ -1823,6 +1824,11 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
     S.T1 = S.Cc + 128 * 128;
     S.T2 = S.T1 + 128 * 128;
     S.T3 = S.T2 + 128 * 128;
+    if (pq >= 3 * 128 * 128 && !(P.fast & 64)) {
+        // the Gram matrix, the reflector store and the check matrix take the place of the fused merge's T buffer / the LQ copy
+        // (dead by the time they are written): 288 KB less footprint per train, and the lines are warm
+        S.Ga = S.M2; S.Gb = S.M2 + 128 * 128; S.T2 = S.M2 + 2 * 128 * 128;
+    }
 
     // fused apply: the right core is still A_{k+1} x_{k+1}.  Wide steps with r_mid >= p get the fused merge below; the
     // others (first steps of the ramp that are tall, tiny cores) write the core out first and proceed as usual.
