@@ -188,10 +188,10 @@ __device__ __forceinline__ int sturm_count(const double (&dreg)[N / 16], const d
     for (int g = 0; g < N / 16; ++g) {
         unsigned int bits = 0;
 #define EIG_ST(j) {                                                                                               \
-            double tt = 0.0, dmx = nx;                                                                            \
-            fmac_bcast<j>(tt, ereg[g], pp);                       /* -e_{i-1}^2 p_{i-1} */                         \
+            double dmx = nx;                                                                                      \
             fmac_bcast<j>(dmx, dreg[g], one);                     /* d_i - x in one rounding */                    \
-            const double pn = fma(dmx, pc, tt);                                                                   \
+            double pn = dmx * pc;                                                                                 \
+            fmac_bcast<j>(pn, ereg[g], pp);                       /* ... - e_{i-1}^2 p_{i-1}: one instruction fewer than forming the product apart */ \
             z |= (pn == 0.0);                                                                                     \
             bits = __builtin_amdgcn_alignbit(bits, (unsigned int)(__double_as_longlong(pn) >> 32), 31);           \
             pp = pc; pc = pn; }
