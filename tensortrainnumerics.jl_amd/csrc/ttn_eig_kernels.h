@@ -400,7 +400,9 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
     // RPL*rc + RPL-1 of both — the dot products v_k' z are reductions over the 16 lanes of a row (4 DPP adds each): no LDS
     // reduction and no barrier in the loop.  The reflectors are staged in LDS once (the D+ / D- arrays are dead after the load of Z).
     lds_f64 *Dp = L, *Dm = L + 64 * 128;
-    const int rc = lane & 15, col0 = 8 * (wave & 7) + 2 * (lane >> 4);
+    // lane groups as in the Jacobi (grp_sum): the 16 lanes {B + 4g + 16k} form group g; member index rc; the 16-lane sums of the
+    // two dot products per reflector then run on the matrix pipe (2 x 2 v_mfma_f64_4x4x4 instead of 2 x 12 VALU instructions)
+    const int rc = (lane & 3) | ((lane >> 4) << 2), col0 = 8 * (wave & 7) + 2 * ((lane >> 2) & 3);
     double z[2][RPL];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -429,7 +431,7 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int t = 0; t < RPL; ++t) { s0 = fma(vk[t], z[0][t], s0); s1 = fma(vk[t], z[1][t], s1); }
-            const double t0 = row16_sum(s0) * bk, t1 = row16_sum(s1) * bk;
+            const double t0 = grp_sum(s0) * bk, t1 = grp_sum(s1) * bk;
 #pragma unroll
             for (int t = 0; t < RPL; ++t) { z[0][t] = fma(-t0, vk[t], z[0][t]); z[1][t] = fma(-t1, vk[t], z[1][t]); }
         }
