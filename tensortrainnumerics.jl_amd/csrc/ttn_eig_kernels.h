@@ -107,8 +107,12 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
         lds_barrier();                                             // v_k, row k+1 (xnext) are visible
         // p = A v (partial over the thread's 16 columns): lane l of a row of 16 lanes holds v[16c + l], the DPP multiply-add
         // broadcasts it — 2 LDS reads per thread and step instead of 48
+        // A wave owns 64 rows of one 16-column chunk.  Once all its columns are <= k (v is zero there and the entries are never read
+        // again) or all its rows are <= k (finished rows: their w only feeds dead entries), it has nothing left to do but to keep its
+        // partial sums at zero: on average 7 of the 16 waves (N = 128) still work, and the phase is bound by the fp64 multiply-adds.
+        const bool live = actv && (16 * (c + 1) > k + 1) && ((TWO ? 64 * (wave & 1) : 0) + 63 > k);
         double vreg = 0.0;
-        if (actv) {
+        if (live) {
             vreg = vL[16 * c + (lane & 15)];
             double pp = 0.0;
             asm volatile("s_nop 1");
@@ -116,7 +120,7 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
             EIG_BCAST16(EIG_MV)
 #undef EIG_MV
             part[c * 128 + i] = pp;
-        }
+        } else if (actv) part[c * 128 + i] = 0.0;
         lds_barrier();
         double v0 = 0.0, v1 = 0.0, w0 = 0.0, w1 = 0.0;
         if (wave == 0) {
@@ -147,7 +151,7 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
             const double x0 = (lane > kk) ? c0 : 0.0, x1 = (TWO && lane + 64 > kk) ? c1 : 0.0;
             tridiag_reflector(kk, x0, x1, xk1, lane, vN, Vst, dg, e, beta, dgk);
         }
-        if (actv) {
+        if (live) {
             // A -= v w' + w v'
             const double wreg = wL[16 * c + (lane & 15)];
             const double nvi = -vL[i], nwi = -wL[i];
