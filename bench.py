@@ -273,7 +273,7 @@ def main():
         # HBM traffic of the dominant kernel comes from the committed rocprofv3 PMC passes of THIS command line
         # (counters cannot be read from inside the process); only reported when the configuration matches.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01n_k_compress_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01o_k_compress_traffic.json")
         if os.path.exists(tpath) and (d, r, B, world) == (30, 64, 1024, 1):
             with open(tpath) as fh:
                 traffic = json.load(fh)["traffic_bytes_per_launch_upper"]
