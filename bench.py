@@ -2,28 +2,40 @@
 """bench.py — "QTT Laplacian apply + round" throughput in TT cores per second on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--d 30] [--rank 64]
+                    [--shard trains|cores] [--op compress|apply|hadamard|add|scale|dot|orthogonalize]
 
 One STEP = one pass of the hot path over one batch of B independent synthetic trains resident in HBM:
     y_b = tt_compress!(Δ(d) * x_b, rank)       for b = 1..B      (src/solvers/euler.jl:55's operator)
-i.e. ttn_apply (HBM-bound streaming kernel) + ttn_compress (one persistent workgroup per train, fp64
-dense linear algebra: merge GEMM -> Householder LQ -> one-sided Jacobi SVD -> truncate -> split).
+as ONE launch of ttn_apply_compress: the apply (src/tt_operations.jl:101-111) is fused into the first L->R
+sweep of the persistent k_compress kernel (src/tt_tools.jl:743-789), y = Δx never exists in HBM.
 value = (#ranks * B * d) / (max-over-ranks wall time per step)   [TT cores / s], inputs already in HBM.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): trains are independent, so they are
-sharded across ranks with no data-path collective (weak scaling: B trains per GPU); torch.distributed
-(RCCL) is only used for the barriers and the max-over-ranks reduction of the timing.
+Multi-GPU: one process per GPU.  Launched by `python -m torch.distributed.run ... bench.py --gpus N` (the driver) the
+ranks come from RANK / WORLD_SIZE; launched as plain `python bench.py --gpus N` this process starts the N workers ITSELF
+(a torchrun child, before anything here touches a GPU) and relays their output.  A line whose n_gpus would differ from
+--gpus is refused.  Trains are independent, so they shard across ranks with no data-path collective (weak scaling:
+B trains per GPU); torch.distributed (RCCL) carries only barriers and the max-over-ranks timing reduction.
+`--shard cores` measures the core-wise sharded pipeline (BASELINE config C4) instead.
 
 The JSON line also carries
-  roofline     for the dominant kernel (k_compress): algorithmic fp64 flops of the sweep (SURVEY §8d:
-               merge GEMMs + Golub–Van-Loan thin-SVD count, evaluated on the actual rank profile) x B
-               per launch / average launch duration measured with HIP events on the library's stream;
-  cpu_baseline the CPU oracle ("port": NumPy + LAPACK gesdd, the reference algorithm WITHOUT the
-               discarded per-bond orthogonalize) timed on this box's host cores, one train per core;
-  single_train the same step with B = 1 (latency of one train; one workgroup = one CU is busy).
+  roofline     for the dominant kernel (k_compress): algorithmic fp64 flops of the sweep (merge GEMMs +
+               Golub–Van-Loan thin-SVD count, evaluated on the actual rank profile) x B per launch / average launch
+               duration measured with HIP events on the library's stream; `traffic` = HBM bytes per launch from the
+               committed rocprofv3 PMC passes of this command (profiles/k_compress_traffic.json, written by
+               scratch/collect_profiles.sh — counters cannot be read from inside the process);
+  cpu_baseline the CPU oracle ("port": NumPy + LAPACK gesdd, the reference algorithm WITHOUT the discarded per-bond
+               orthogonalize) timed on this box's host cores: one train per core on all cores, and one train with
+               all BLAS threads; value = the best;
+  batch_sweep  the same step at B = 1, 8, 64, 256 (B = 1: latency of one train);
+  verified     number of trains of the timed batch downloaded after the timed region and checked against the oracle
+               (ranks exact, tensor difference <= 1e-9).
+`--op X` prints one roofline line for another hot-path kernel instead (HBM-bound: apply / hadamard / add / scale;
+fp64-MFMA-bound: dot / orthogonalize) on C3-shaped batches.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,7 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6     # AMD MI355X public fp64 vector = matrix peak; MI355X_MICROARCH.md has no fp64 row
+FP64_PEAK_TFLOPS = 78.6     # AMD MI355X public fp64 vector = matrix peak; scratch/mfma_peak.hip measures 128 flop/clk/CU = the same
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E ~8 TB/s (about 6.3 TB/s achievable by a read stream)
 
 
 def sweep_algorithmic_flops(d, rks_in, rks_out_after_lr, max_bond, n=2):
@@ -54,13 +67,17 @@ def sweep_algorithmic_flops(d, rks_in, rks_out_after_lr, max_bond, n=2):
     return total
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# cpu_baseline leg (the ONLY place besides `verify` where bench.py touches oracle/, and only as the thing timed beside
+# the GPU number / the checker — never in the product path)
+# ------------------------------------------------------------------------------------------------------------------
 def _cpu_worker(args):
-    d, rank, seed, reps, faithful = args
+    d, rank, seed, reps, faithful, threads = args
     from threadpoolctl import threadpool_limits
     import ttn_amd as T
     from oracle import tt_oracle as O
     from tests.helpers import to_oracle
-    with threadpool_limits(limits=1):
+    with threadpool_limits(limits=threads):
         x = to_oracle(T.rand_tt((2,) * d, rank, seed=seed))
         A = O.Delta(d)
         t0 = time.perf_counter()
@@ -69,39 +86,100 @@ def _cpu_worker(args):
         return time.perf_counter() - t0
 
 
+def host_info():
+    info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    info["cpu_model"] = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        from threadpoolctl import threadpool_info
+        import numpy  # noqa: F401  (loads the BLAS the oracle uses)
+        import scipy.linalg  # noqa: F401
+        info["blas"] = sorted({"%s %s (%s, %s threads)" % (p.get("internal_api"), p.get("version"), p.get("architecture"), p.get("num_threads"))
+                               for p in threadpool_info() if p.get("user_api") == "blas"})
+    except Exception:
+        pass
+    return info
+
+
 def cpu_baseline(d, rank, budget_s=20.0):
-    """Oracle (reference algorithm, lean: without the discarded orthogonalize) on the host cores,
-    one independent train per process, BLAS pinned to 1 thread per process."""
+    """Oracle (reference algorithm, lean: without the discarded orthogonalize) on ALL host cores this process may use:
+    (i) one independent train per process, 1 BLAS thread each; (ii) one train with all BLAS threads.  value = best."""
     import multiprocessing as mp
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
-    t1 = _cpu_worker((d, rank, 30, 1, False))                     # calibrate on one train
+    cores = max(1, len(os.sched_getaffinity(0)))
+    t1 = _cpu_worker((d, rank, 30, 1, False, 1))                  # calibrate on one train, one thread
     reps = max(1, min(8, int(budget_s / max(t1, 1e-3))))
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, [(d, rank, 30, 1, False, 1)] * cores)           # warm the workers (imports, page-in)
         t0 = time.perf_counter()
-        pool.map(_cpu_worker, [(d, rank, 30 + c, reps, False) for c in range(cores)])
+        pool.map(_cpu_worker, [(d, rank, 30 + c, reps, False, 1) for c in range(cores)])
         wall = time.perf_counter() - t0
-    # includes process start-up; subtract nothing (conservative for the GPU/CPU ratio is to favour the CPU,
-    # so also report the single-core figure measured without any pool overhead)
     multi = cores * reps * d / wall
     single = d / t1
-    value = max(multi, single * 1.0)
+    tall = _cpu_worker((d, rank, 30, max(1, min(3, reps)), False, cores)) / max(1, min(3, reps))
+    one_train_all_threads = d / tall
+    cands = [(multi, cores, "%d procs x 1 BLAS thread" % cores), (single, 1, "1 proc x 1 BLAS thread"),
+             (one_train_all_threads, cores, "1 proc x %d BLAS threads" % cores)]
+    value, used, how = max(cands)
     # the reference-FAITHFUL flavour (with the orthogonalize that _tt_bond_truncate! computes and tt_compress! discards,
-    # src/tt_tools.jl:769,779) on one train and one core, if the lean timing says it fits ~15 s: the lean figure above is
-    # the conservative baseline (it makes the CPU look faster than the reference is)
+    # src/tt_tools.jl:769,779) on one train and one core, if the lean timing says it fits ~15 s
     faithful = None
     if t1 * 12 < 15.0:
         try:
-            faithful = d / _cpu_worker((d, rank, 30, 1, True))
+            faithful = d / _cpu_worker((d, rank, 30, 1, True, 1))
         except Exception:
             faithful = None
-    out = {"value": round(value, 2), "unit": "TT cores/s", "cores": cores if multi >= single else 1, "kind": "port",
-           "sample": f"{cores} procs x {reps} trains of d={d} rank={rank} (lean oracle, NumPy+LAPACK gesdd, 1 BLAS thread/proc); "
-                     f"single-core {single:.1f} cores/s"
-                     + (f"; reference-faithful (with the discarded orthogonalize) single-core {faithful:.1f} cores/s" if faithful else "")}
+    out = {"value": round(value, 2), "unit": "TT cores/s", "cores": used, "kind": "port",
+           "sample": f"{cores} procs x {reps} trains of d={d} rank={rank} (lean oracle = reference algorithm without the discarded "
+                     f"orthogonalize, NumPy+LAPACK gesdd); best of: {how}",
+           "trains_per_core_all_cores": round(multi, 2), "one_train_one_thread": round(single, 2),
+           "one_train_all_threads": round(one_train_all_threads, 2), "host": host_info()}
     if faithful:
         out["faithful_single_core"] = round(faithful, 2)
     return out
+
+
+def verify_against_oracle(T, dy, seeds_by_slot, d, r, slots):
+    """Download `slots` of the timed batch and compare with the oracle on the same seeds: ranks exact, ||y_gpu - y_cpu|| / ||y_cpu||
+    <= 1e-9 (the parity bar of tests/test_gpu_parity.py).  Raises on a mismatch; returns the number of trains checked."""
+    from oracle import tt_oracle as O
+    from tests.helpers import to_oracle, tt_rel_diff
+    A = O.Delta(d)
+    worst = 0.0
+    for b in slots:
+        got = to_oracle(dy.download(b))
+        ref = O.tt_compress_(O.apply(A, to_oracle(T.rand_tt((2,) * d, r, seed=seeds_by_slot[b]))), r)
+        if got.ttv_rks != ref.ttv_rks:
+            raise SystemExit(f"bench.py: train {b} (seed {seeds_by_slot[b]}): ranks {got.ttv_rks} != oracle {ref.ttv_rks}")
+        err = tt_rel_diff(got, ref)
+        worst = max(worst, err)
+        if not err <= 1e-9:
+            raise SystemExit(f"bench.py: train {b} (seed {seeds_by_slot[b]}): rel. difference to the oracle {err:.3e} > 1e-9")
+    return len(slots), worst
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher
+# ------------------------------------------------------------------------------------------------------------------
+def launch_workers(n, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as a FRESH child (torch.distributed.run)
+    — this process has not touched a GPU and never will — relay its output and exit with its code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def bench_core_sharded(args, T, D, torch, dist, rank, world, red_device):
@@ -163,34 +241,151 @@ def bench_core_sharded(args, T, D, torch, dist, rank, world, red_device):
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# --op: roofline lines of the other hot-path kernels
+# ------------------------------------------------------------------------------------------------------------------
+def bench_op(args, T, D):
+    """One C3-shaped batch, one kernel: bytes (or flops) / HIP-event time / peak.  Algorithmic bytes = the cores read + the cores
+    written, once each; algorithmic flops of dot = sum_k 2 n (rA rB rB' + rA rA' rB'), of orthogonalize = the
+    Householder QR/LQ count 2 m n^2 - 2/3 n^3 per core plus forming Q (the same again) plus the R / L carry GEMM."""
+    import numpy as np
+    d, r, B, op = args.d, args.rank, args.batch, args.op
+    dims = (2,) * d
+    A = T.Delta(d)
+    dA = T.DeviceTTO(A)
+    x0 = T.rand_tt(dims, r, seed=30)
+    xr = list(x0.ttv_rks)
+    dx = T.DeviceTT(dims, xr, batch=B)
+    for b in range(B):
+        dx.upload(b, T.rand_tt(dims, r, seed=30 + b))
+    core_bytes = lambda rk: 8.0 * sum(2 * rk[k] * rk[k + 1] for k in range(d))          # noqa: E731
+    bound, flops, nbytes, kernel = "hbm", 0.0, 0.0, "k_" + op
+    if op == "apply":
+        yr = [a * c for a, c in zip(A.tto_rks, xr)]
+        dy = T.DeviceTT(dims, yr, batch=B)
+        run = lambda: D.apply(dA, dx, dy)                                                 # noqa: E731
+        nbytes = B * (core_bytes(xr) + core_bytes(yr)) + 8.0 * sum(c.size for c in A.tto_vec)
+    elif op == "hadamard":
+        # the Hadamard square of a rank-r train has rank r^2: C3-shaped INPUT ranks would need 4096-rank outputs (2 GB per train);
+        # use the rank profile min(8, ...) -> output ranks 64, the size class of the headline trains
+        h0 = T.rand_tt(dims, 8, seed=30)
+        hr = list(h0.ttv_rks)
+        da = T.DeviceTT.from_host(h0, batch=B)
+        db = T.DeviceTT.from_host(T.rand_tt(dims, 8, seed=31), batch=B)
+        zr = [p * q for p, q in zip(hr, hr)]
+        dz = T.DeviceTT(dims, zr, batch=B)
+        run = lambda: D.hadamard(da, db, dz)                                              # noqa: E731
+        nbytes = B * (2 * core_bytes(hr) + core_bytes(zr))
+    elif op == "add":
+        dx2 = T.DeviceTT(dims, xr, batch=B)
+        D.scale(1.0, dx, dx2)
+        zr = [p + q for p, q in zip(xr, xr)]
+        zr[0] = zr[-1] = 1
+        dz = T.DeviceTT(dims, zr, batch=B)
+        run = lambda: D.add(dx, dx2, dz)                                                  # noqa: E731
+        nbytes = B * (2 * core_bytes(xr) + core_bytes(zr))
+    elif op == "scale":
+        dz = T.DeviceTT(dims, xr, batch=B)
+        run = lambda: D.scale(1.5, dx, dz)                                                # noqa: E731
+        nbytes = B * 2 * core_bytes(xr)
+    elif op == "dot":
+        bound = "mfma"
+        run = lambda: D.dot(dx, dx)                                                       # noqa: E731
+        flops = B * sum(2.0 * 2 * (xr[k] * xr[k] * xr[k + 1] + xr[k] * xr[k + 1] * xr[k + 1]) for k in range(d))
+        nbytes = B * 2 * core_bytes(xr)
+    elif op == "orthogonalize":
+        bound = "mfma"
+        dz = T.DeviceTT(dims, xr, batch=B)
+        run = lambda: D.orthogonalize(dx, 1, dz)                                          # noqa: E731
+        for k in range(1, d):           # right-to-left LQ sweep to site 1: core k as r_{k} x (n r_{k+1}) -> m = n r_{k+1}, n_ = r_k
+            m_, n_ = 2 * xr[k + 1], xr[k]
+            if m_ < n_:
+                m_, n_ = n_, m_
+            flops += 2.0 * (2.0 * m_ * n_ * n_ - 2.0 / 3.0 * n_ ** 3) + 2.0 * 2 * xr[k - 1] * xr[k] * n_
+        flops *= B
+        nbytes = B * 2 * core_bytes(xr)
+    else:
+        raise SystemExit("unknown --op " + op)
+    for _ in range(max(1, args.warmup)):
+        run()
+    D.sync()
+    ms = []
+    for i in range(args.steps):
+        D.event_record(2 * i)
+        run()
+        D.event_record(2 * i + 1)
+    D.sync()
+    ms = [D.event_elapsed_ms(2 * i, 2 * i + 1) for i in range(args.steps)]
+    t = float(np.median(ms)) / 1e3
+    if bound == "hbm":
+        achieved, peak, unit = nbytes / t / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        achieved, peak, unit = flops / t / 1e12, FP64_PEAK_TFLOPS, "TFLOP/s"
+    res = {"metric": "TT cores/sec, %s on C3-shaped trains (d=%d rank-%d)" % (op, d, r), "value": round(B * d / t, 1), "unit": "TT cores/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "%s over a batch of %d trains resident in HBM" % (op, B), "d": d, "rank": r, "batch_per_gpu": B},
+           "roofline": {"bound": bound, "kernel": kernel, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                        "frac": round(achieved / peak, 4), "traffic": None, "algorithmic_bytes_per_launch": nbytes,
+                        "algorithmic_flops_per_launch": flops, "avg_launch_ms": round(t * 1e3, 4)}}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="independent trains per GPU per step (4 per CU: the hardware dispatcher then balances the 498-570 Jacobi sweeps per train)")
+    ap.add_argument("--batch", type=int, default=1024, help="independent trains per GPU per step")
     ap.add_argument("--d", type=int, default=30)
     ap.add_argument("--rank", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement")
+    ap.add_argument("--no-single", action="store_true", help="skip the batch sweep B = 1, 8, 64, 256")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run check of downloaded trains against the oracle")
     ap.add_argument("--shard", default="trains", choices=["trains", "cores"],
                     help="N>1: 'trains' (default) = independent trains per GPU, no data-path collective; 'cores' = every chain cut "
                          "core-wise into N segments with boundary-core hand-offs (pipeline.py; micro-batches of --batch trains)")
     ap.add_argument("--microbatches", type=int, default=0, help="--shard cores: micro-batches in flight per step (default 2*N)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                                                         "the multi-process path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--op", default="compress", choices=["compress", "apply", "hadamard", "add", "scale", "dot", "orthogonalize"],
+                    help="compress (default) = the headline apply+round step; the others print the roofline line of that kernel alone")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, form the process group, all-reduce the world size and print it (no GPU needed: the "
+                         "launcher test of tests/test_distributed_gloo.py)")
     args = ap.parse_args()
 
+    # ---- launcher: N > 1 without a torchrun environment -> start the ranks as a child BEFORE anything touches a GPU ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line whose n_gpus differs from --gpus")
+
     import torch
+    dist = None
+    if args.launch_check:
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl",
+                                    rank=rank, world_size=world)
+            t = torch.ones(1, dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)
+            n = int(t.item())
+            dist.destroy_process_group()
+        else:
+            n = 1
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": n, "requested": args.gpus}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     ndev = torch.cuda.device_count()
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
-    dist = None
     red_device = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist_mod
@@ -206,14 +401,19 @@ def main():
     T.ensure_init(dev_index)
 
     d, r, B = args.d, args.rank, args.batch
+    if args.op != "compress":
+        if world != 1:
+            raise SystemExit("--op lines are single-GPU measurements")
+        return bench_op(args, T, D)
     if args.shard == "cores":
         return bench_core_sharded(args, T, D, torch, dist, rank, world, red_device)
     A = T.Delta(d)
     dA = T.DeviceTTO(A)
     x0 = T.rand_tt((2,) * d, r, seed=30)
     dx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=B)
-    for b, g in enumerate(T.shard.weak_train_ids(rank, world, B)):   # distinct synthetic trains, seeds 30 + global index
-        dx.upload(b, T.rand_tt((2,) * d, r, seed=30 + g))
+    seeds = [30 + g for g in T.shard.weak_train_ids(rank, world, B)]     # distinct synthetic trains, seeds 30 + global index
+    for b, sd in enumerate(seeds):
+        dx.upload(b, T.rand_tt((2,) * d, r, seed=sd))
     ycap = [a * c for a, c in zip(A.tto_rks, x0.ttv_rks)]
     dy = T.DeviceTT((2,) * d, ycap, batch=B)
 
@@ -250,33 +450,48 @@ def main():
     k_avg_s = sum(kms) / len(kms) / 1e3
     out_rks, _ = dy.ranks(0)
 
-    single = None
+    verified = None
+    if rank == 0 and not args.no_verify:
+        slots = sorted({0, B // 2, B - 1})
+        verified = verify_against_oracle(T, dy, seeds, d, r, slots)
+
+    sweep = None
     if rank == 0 and not args.no_single:
-        sx = T.DeviceTT.from_host(x0)
-        sy = T.DeviceTT((2,) * d, ycap)
-        for _ in range(2):
-            D.apply_compress(dA, sx, sy, r)
-        D.sync()
-        ts = time.perf_counter()
-        nrep = 5
-        for _ in range(nrep):
-            D.apply_compress(dA, sx, sy, r)
-        D.sync()
-        tsingle = (time.perf_counter() - ts) / nrep
-        single = {"value": round(d / tsingle, 1), "unit": "TT cores/s", "ms_per_step": round(tsingle * 1e3, 3), "batch": 1}
+        sweep = []
+        for Bs in (1, 8, 64, 256):
+            sx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=Bs)
+            for b in range(Bs):
+                sx.upload(b, T.rand_tt((2,) * d, r, seed=30 + b))
+            sy = T.DeviceTT((2,) * d, ycap, batch=Bs)
+            for _ in range(2):
+                D.apply_compress(dA, sx, sy, r)
+            D.sync()
+            nrep = 5
+            ts = time.perf_counter()
+            for _ in range(nrep):
+                D.apply_compress(dA, sx, sy, r)
+            D.sync()
+            tb = (time.perf_counter() - ts) / nrep
+            D.compress_status(sy)
+            sweep.append({"batch": Bs, "value": round(Bs * d / tb, 1), "unit": "TT cores/s", "ms_per_step": round(tb * 1e3, 3)})
+            sx.free()
+            sy.free()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = T.shard.cores_per_second(world, B, d, elapsed / args.steps)
         flops = sweep_algorithmic_flops(d, ycap, None, r) * B
         achieved = flops / k_avg_s / 1e12
-        # HBM traffic of the dominant kernel comes from the committed rocprofv3 PMC passes of THIS command line
-        # (counters cannot be read from inside the process); only reported when the configuration matches.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01o_k_compress_traffic.json")
-        if os.path.exists(tpath) and (d, r, B, world) == (30, 64, 1024, 1):
+        # HBM traffic of the dominant kernel: the rocprofv3 PMC passes of THIS command line, as scratch/collect_profiles.sh
+        # wrote them (counters cannot be read from inside the process).  Reported only when the configuration matches.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "k_compress_traffic.json")
+        if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh)["traffic_bytes_per_launch_upper"]
+                tj = json.load(fh)
+            if (tj.get("d"), tj.get("rank"), tj.get("batch"), 1) == (d, r, B, world):
+                traffic = tj.get("traffic_bytes_per_launch")
+                traffic_src = {"file": "profiles/k_compress_traffic.json", "tag": tj.get("tag"), "note": "profile-derived (separate --pmc passes), not measured by this run"}
         res = {
             "metric": "TT cores/sec for QTT Laplacian apply+round, d=%d rank-%d" % (d, r),
             "value": round(value, 1), "unit": "TT cores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -287,13 +502,17 @@ def main():
                        "d": d, "rank": r, "batch_per_gpu": B, "parallelism": "trains sharded over %d GPU(s), no collective" % world,
                        "out_ranks": out_rks},
             "roofline": {"bound": "mfma", "kernel": "k_compress", "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_flops_per_launch": flops, "avg_launch_ms": round(k_avg_s * 1e3, 3),
                          "bond_steps_per_s": round(2 * (d - 1) * B / k_avg_s, 1),
                          "jacobi_sweeps_per_train": sweeps[0]},
         }
-        if single is not None:
-            res["single_train"] = single
+        if verified is not None:
+            res["verified"] = verified[0]
+            res["verified_max_rel_diff"] = float("%.3e" % verified[1])
+        if sweep is not None:
+            res["batch_sweep"] = sweep
+            res["single_train"] = sweep[0]
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(d, r)
         print(json.dumps(res), flush=True)

@@ -8,7 +8,7 @@
 module TTNBackend
 
 using TensorTrainNumerics
-import TensorTrainNumerics: TTvector, TToperator, orthogonalize, tt_compress!, hadamard, add!, r_and_d_to_rks
+import TensorTrainNumerics: TTvector, TToperator, orthogonalize, tt_compress!, _tt_bond_truncate!, hadamard, add!, r_and_d_to_rks, zeros_tt
 import Base: *, +
 
 const LIB = get(ENV, "TTN_LIB", joinpath(@__DIR__, "..", "tensortrainnumerics.jl_amd", "libttn_hip.so"))
@@ -74,6 +74,45 @@ function add!(x::TTvector{Float64, N}, y::TTvector{Float64, N}) where {N}
     z = x + y
     x.ttv_vec = z.ttv_vec; x.ttv_rks = z.ttv_rks; x.ttv_ot = z.ttv_ot
     return x
+end
+
+# a * x — src/tt_operations.jl:256-266 (`x * a`, `-`, `/` are one-liners on top of it in the reference, :268-295, and keep dispatching
+# here).  a == 0 gives zeros_tt(...) with ot reset; otherwise the first core with ot == 0 (else core 1) is scaled and ot is copied.
+function *(a::Float64, x::TTvector{Float64, N}) where {N}
+    y = zeros_tt(Float64, x.ttv_dims, x.ttv_rks)
+    yot = zeros(Int64, N)
+    px, py = _ptrs(x.ttv_vec), _ptrs(y.ttv_vec)
+    GC.@preserve x y px py _chk(ccall((:ttn_scale_f64, LIB), Cint,
+        (Int64, Ptr{Int64}, Float64, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}),
+        N, _dims(x.ttv_dims), a, px, x.ttv_rks, x.ttv_ot, py, yot))
+    y.ttv_ot .= yot
+    return y
+end
+
+# _tt_bond_truncate!(ψ, k; max_bond, truncerr) — src/tt_tools.jl:743-770: mutates cores k, k+1 and ψ.ttv_rks[k+1] in place and
+# RETURNS orthogonalize(ψ; i=k) (:769) like the reference (tt_compress! discards that value, so ttn_compress_f64 never computes it).
+function _tt_bond_truncate!(ψ::TTvector{Float64, N}, k::Int; max_bond::Int = typemax(Int), truncerr::Real = 0.0) where {N}
+    @assert(1 ≤ k < N, "k must be in 1:(N-1)")
+    mb = min(max_bond, typemax(Int64) >> 1)
+    need = zeros(Int64, N + 1)                      # the rank of a rank-deficient bond may grow to min(n r_left, n r_right, max_bond)
+    _chk(ccall((:ttn_compress_rank_bound, LIB), Cint,
+        (Int64, Ptr{Int64}, Ptr{Int64}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}),
+        N, _dims(ψ.ttv_dims), ψ.ttv_rks, mb, 1, k, need, C_NULL))
+    bufs = [zeros(Float64, ψ.ttv_dims[j] * need[j] * need[j + 1]) for j in 1:N]
+    for j in 1:N
+        copyto!(bufs[j], vec(ψ.ttv_vec[j]))
+    end
+    rks = copy(ψ.ttv_rks)
+    pb = Ptr{Float64}[pointer(c) for c in bufs]
+    GC.@preserve bufs pb _chk(ccall((:ttn_bond_truncate_f64, LIB), Cint,
+        (Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Int64}, Int64, Int64, Float64),
+        N, _dims(ψ.ttv_dims), pb, rks, k, mb, Float64(truncerr)))
+    for j in (k, k + 1)                             # only these two slots change (:764-767)
+        n = ψ.ttv_dims[j]
+        ψ.ttv_vec[j] = reshape(bufs[j][1:(n * rks[j] * rks[j + 1])], n, rks[j], rks[j + 1])
+    end
+    ψ.ttv_rks[k + 1] = rks[k + 1]
+    return orthogonalize(ψ; i = k)
 end
 
 # orthogonalize(x; i=1) — src/tt_tools.jl:511-543

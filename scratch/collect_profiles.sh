@@ -1,41 +1,112 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for one round tag:  bash scratch/collect_profiles.sh r01i   (run on the GPU box from the repo root)
+# Collects the rocprofv3 evidence for one round tag:  bash scratch/collect_profiles.sh r02a   (run on the GPU box from the repo root)
+#  1. rocprofv3 --kernel-trace --stats around the default bench command        -> gpurun_out/<tag>_bench_b1024_kernel_stats.csv
+#  2. one --pmc pass per counter set (never combined with the trace domains)   -> gpurun_out/<tag>_pmc.json
+#  3. gpurun_out/k_compress_traffic.json = the UNTAGGED file bench.py reads `roofline.traffic` from (copy it, and the tagged
+#     summaries, to profiles/ and commit them; nothing here is ever edited by hand)
+#  OPS=1: also a --kernel-trace --stats pass + FETCH/WRITE passes for each `bench.py --op X` line -> gpurun_out/<tag>_op_<X>.json
 set -e
-TAG=${1:-r01x}
+TAG=${1:-r02x}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-single"
+CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-single --no-verify"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $CMD > $OUT/line.json 2> $OUT/stats.err
 for C in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F64"; do
   N=$(echo $C | tr ' ' '_')
   rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/pmc_$N -o p -- $CMD > $OUT/pmc_$N.line 2> $OUT/pmc_$N.err
 done
+if [ -n "$OPS" ]; then
+  for OP in apply hadamard add scale dot orthogonalize; do
+    OCMD="python3 $ROOT/bench.py --op $OP --steps 5 --warmup 2 --batch 256"
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/op_$OP/stats -o s -- $OCMD > $OUT/op_$OP.line 2> $OUT/op_$OP.err
+    for C in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/op_$OP/pmc_$C -o p -- $OCMD > /dev/null 2>> $OUT/op_$OP.err
+    done
+  done
+fi
 cd $ROOT
-find $OUT -type f | head -30
 tail -3 $OUT/stats.err
 python3 - "$OUT" "$TAG" <<'PY'
-import csv, glob, json, sys, os
+import csv, glob, json, sys, os, subprocess
 out, tag = sys.argv[1], sys.argv[2]
-res = {"k_compress": {}}
-st = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)
-if st:
+dst = os.path.dirname(out)
+
+
+def kernel_stats(d, name):
+    st = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
+    if not st:
+        return None, None
     rows = list(csv.DictReader(open(st[0])))
-    open(os.path.join(os.path.dirname(out), f"{tag}_bench_b1024_kernel_stats.csv"), "w").write(open(st[0]).read())
     for r in rows:
-        if "k_compress" in r.get("Name", ""):
-            res["k_compress"]["avg_ns"] = float(r["AverageNs"]); res["k_compress"]["calls"] = int(r["Calls"])
-for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
-    acc = {}
-    for r in csv.DictReader(open(f)):
-        if "k_compress" not in r["Kernel_Name"]: continue
-        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        res["k_compress"][k + "_per_launch"] = sum(v) / len(v)
-        res["k_compress"]["launches"] = len(v)
-json.dump(res, open(os.path.join(os.path.dirname(out), f"{tag}_pmc_raw.json"), "w"), indent=1)
-print(json.dumps(res, indent=1))
-print(open(out + "/line.json").read()[:400])
+        if name in r.get("Name", ""):
+            return st[0], {"avg_ns": float(r["AverageNs"]), "calls": int(r["Calls"])}
+    return st[0], None
+
+
+def counters(pattern, name):
+    res = {}
+    for f in glob.glob(pattern, recursive=True):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if name not in r["Kernel_Name"]:
+                continue
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            res[k + "_per_launch"] = sum(v) / len(v)
+            res["launches"] = len(v)
+    return res
+
+
+res = {"tag": tag, "k_compress": {}}
+path, ks = kernel_stats(out + "/stats", "k_compress")
+if path:
+    open(os.path.join(dst, f"{tag}_bench_b1024_kernel_stats.csv"), "w").write(open(path).read())
+if ks:
+    res["k_compress"].update(ks)
+res["k_compress"].update(counters(out + "/pmc_*/**/*counter_collection.csv", "k_compress"))
+line = {}
+try:
+    line = json.loads([ln for ln in open(out + "/line.json") if ln.startswith("{")][-1])
+except Exception:
+    pass
+res["bench_line_under_profiler"] = line
+kc = res["k_compress"]
+if "SQ_BUSY_CYCLES_per_launch" in kc and "avg_ns" in kc:
+    # SIMD-cycles available = 4 SIMDs x 256 CUs x kernel cycles (2.4 GHz); the SQ counters are summed over SEs/XCDs
+    simd_cycles = 4 * 256 * kc["avg_ns"] * 2.4
+    res["derived"] = {"kernel_ms": kc["avg_ns"] / 1e6, "simd_cycles_available": simd_cycles,
+                      "mfma_pipe_busy_frac": kc.get("SQ_VALU_MFMA_BUSY_CYCLES_per_launch", 0) / simd_cycles,
+                      "valu_busy_frac": 4 * kc.get("SQ_ACTIVE_INST_VALU_per_launch", 0) / simd_cycles}
+json.dump(res, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+# the untagged traffic file bench.py reads.  FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3 derived metrics).  gfx950: FETCH_SIZE
+# reports half the bytes of wide coalesced reads and is uncalibrated for the 8-byte-per-lane strided reads that dominate
+# k_compress (MI355X_MICROARCH.md, HBM): traffic = WRITE + FETCH_raw is the lower figure, WRITE + 2 FETCH_raw the upper one.
+if "FETCH_SIZE_per_launch" in kc and "WRITE_SIZE_per_launch" in kc:
+    cfg = line.get("config", {})
+    w, f = kc["WRITE_SIZE_per_launch"] * 1024.0, kc["FETCH_SIZE_per_launch"] * 1024.0
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    json.dump({"kernel": "k_compress", "tag": tag, "commit": commit or None, "d": cfg.get("d"), "rank": cfg.get("rank"), "batch": cfg.get("batch_per_gpu"),
+               "command": "bench.py --steps 3 --warmup 1 --no-cpu --no-single --no-verify under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
+               "write_bytes_per_launch": w, "fetch_bytes_per_launch_raw": f,
+               "traffic_bytes_per_launch": w + f, "traffic_bytes_per_launch_upper": w + 2 * f,
+               "note": "raw FETCH_SIZE under-counts wide coalesced reads by 1/2 on gfx950 and is uncalibrated for 8-byte strided reads: "
+                       "traffic_bytes_per_launch = WRITE + FETCH_raw (lower), _upper = WRITE + 2 FETCH_raw"},
+              open(os.path.join(dst, "k_compress_traffic.json"), "w"), indent=1)
+for opline in sorted(glob.glob(out + "/op_*.line")):
+    op = os.path.basename(opline)[3:-5]
+    kname = {"apply": "k_apply", "hadamard": "k_hadamard", "add": "k_add", "scale": "k_scale", "dot": "k_dot", "orthogonalize": "k_orthogonalize"}[op]
+    rec = {"tag": tag, "op": op, "kernel": kname}
+    try:
+        rec["bench_line_under_profiler"] = json.loads([ln for ln in open(opline) if ln.startswith("{")][-1])
+    except Exception:
+        pass
+    _, ks = kernel_stats(out + f"/op_{op}/stats", kname)
+    if ks:
+        rec.update(ks)
+    rec.update(counters(out + f"/op_{op}/pmc_*/**/*counter_collection.csv", kname))
+    json.dump(rec, open(os.path.join(dst, f"{tag}_op_{op}.json"), "w"), indent=1)
+print(json.dumps(res, indent=1)[:3000])
 PY
-rm -rf $OUT/stats $OUT/pmc_*/   # raw traces are large; the summaries above are what is kept
+rm -rf $OUT/stats $OUT/pmc_*/ $OUT/op_*/   # raw traces are large; the summaries above are what is kept

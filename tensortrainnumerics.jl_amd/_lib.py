@@ -25,6 +25,7 @@ TTN_ERR_ARG = -6
 TTN_ERR_NOT_INIT = -7
 TTN_ERR_UNSUPPORTED = -8
 TTN_ERR_NO_CONVERGENCE = -9
+TTN_ERR_SINGULAR = -10
 
 i64 = C.c_int64
 p_i64 = C.POINTER(C.c_int64)

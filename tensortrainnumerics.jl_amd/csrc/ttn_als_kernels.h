@@ -274,7 +274,6 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
     double* Tm = scr + P.offTm;
     double* Qb = scr + P.offQb;
     double* Rb = scr + P.offRb;
-    if (tid == 0) P.status[b] = 0;
     // the ranks are fixed (als.jl:177): every train must carry exactly the handle's ranks
     {
         const long long* xr = P.x.rks + (long long)b * (d + 1);
@@ -488,7 +487,7 @@ __global__ void __launch_bounds__(TTN_WG) k_mals_linsolve(MalsArgs Q) {
     double* T2 = scr + P.offT2;
     double* M2 = scr + Q.offM2;
     int* piv = reinterpret_cast<int*>(scr + P.offPiv);
-    if (tid == 0) { P.status[b] = 0; Q.C.sweep_stats[b] = 0; }
+    if (tid == 0) Q.C.sweep_stats[b] = 0;
     long long* xr = P.x.rks + (long long)b * (d + 1);
     const long long* br_ = P.b.rks + (long long)b * (d + 1);
     AlsEnv E;

@@ -29,8 +29,6 @@ hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 std::string g_err = "";
 void* g_scratch = nullptr;
 size_t g_scratch_bytes = 0;
-int* g_status = nullptr;      // per-train status + sweep stats (2 * g_status_cap ints)
-int g_status_cap = 0;
 double* g_dout = nullptr;     // per-train double outputs (dot)
 std::vector<hipEvent_t> g_slots;   // ttn_event_record slots
 int g_prof_batch = 0;
@@ -66,11 +64,6 @@ int ensure_scratch(size_t bytes) {
     return TTN_OK;
 }
 int ensure_batch_bufs(int batch) {
-    if (batch > g_status_cap) {
-        if (g_status) { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipFree(g_status)); }
-        HIPCHK(hipMalloc((void**)&g_status, sizeof(int) * 2 * batch));
-        g_status_cap = batch;
-    }
     if (batch > g_dout_cap) {
         if (g_dout) { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipFree(g_dout)); }
         HIPCHK(hipMalloc((void**)&g_dout, sizeof(double) * batch));
@@ -94,6 +87,8 @@ struct ttn_tt_s {
     long long* d_cap = nullptr;
     int* d_dims = nullptr;
     std::vector<int64_t> ot;                  // [batch][d] host-side gauge flags (never data dependent)
+    int* d_status = nullptr;                  // [2][batch]: failure codes of the dense kernels that wrote THIS handle — sticky (kernels only
+                                              // store non-zero codes, ttn_compress_status reads and clears) — then the sweep counts of the last launch
     // singular-value capture
     bool sv_on = false;
     double* d_sv = nullptr;
@@ -177,9 +172,8 @@ int ttn_finalize(void) {
     if (!g_init) return TTN_OK;
     hipStreamSynchronize(g_stream);
     if (g_scratch) hipFree(g_scratch);
-    if (g_status) hipFree(g_status);
     if (g_dout) hipFree(g_dout);
-    g_scratch = nullptr; g_scratch_bytes = 0; g_status = nullptr; g_status_cap = 0; g_dout = nullptr; g_dout_cap = 0;
+    g_scratch = nullptr; g_scratch_bytes = 0; g_dout = nullptr; g_dout_cap = 0;
     hipEventDestroy(g_ev0); hipEventDestroy(g_ev1);
     for (auto e : g_slots) if (e) hipEventDestroy(e);
     g_slots.clear();
@@ -287,7 +281,8 @@ int ttn_tt_create(int64_t d, const int64_t* dims, const int64_t* cap_rks, int64_
         (e = hipMalloc((void**)&h->d_off, sizeof(long long) * (d + 1))) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_cap, sizeof(long long) * (d + 1))) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_rks, sizeof(long long) * (size_t)batch * (d + 1))) != hipSuccess ||
-        (e = hipMalloc((void**)&h->d_dims, sizeof(int) * d)) != hipSuccess) {
+        (e = hipMalloc((void**)&h->d_dims, sizeof(int) * d)) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_status, sizeof(int) * 2 * (size_t)batch)) != hipSuccess) {
         ttn_tt_free(h);
         return hipfail(e, "hipMalloc(ttn_tt)");
     }
@@ -296,6 +291,7 @@ int ttn_tt_create(int64_t d, const int64_t* dims, const int64_t* cap_rks, int64_
     HIPCHK(hipMemcpyAsync(h->d_rks, rk0.data(), sizeof(long long) * rk0.size(), hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemcpyAsync(h->d_dims, idims.data(), sizeof(int) * d, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(h->d_data, 0, sizeof(double) * (size_t)o * batch, g_stream));
+    HIPCHK(hipMemsetAsync(h->d_status, 0, sizeof(int) * 2 * (size_t)batch, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     *out = h;
     return TTN_OK;
@@ -311,6 +307,7 @@ int ttn_tt_free(ttn_tt_t h) {
     if (h->d_rks) hipFree(h->d_rks);
     if (h->d_dims) hipFree(h->d_dims);
     if (h->d_sv) hipFree(h->d_sv);
+    if (h->d_status) hipFree(h->d_status);
     delete h;
     return TTN_OK;
 }
@@ -419,7 +416,7 @@ int ttn_tt_copy(ttn_tt_t dst, ttn_tt_t src) {
     for (int k = 0; k < d; ++k) maxsz = std::max<long long>(maxsz, (long long)src->dims[k] * src->bound[k] * src->bound[k + 1]);
     hipLaunchKernelGGL(k_ranks_copy, dim3(src->batch), dim3(64), 0, g_stream, dst->dev(), src->dev());
     dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((maxsz + TTN_STREAM_TB - 1) / TTN_STREAM_TB, 2048)), (unsigned)d, (unsigned)src->batch);
-    hipLaunchKernelGGL(k_scale, grid, dim3(TTN_STREAM_TB), 0, g_stream, src->dev(), dst->dev(), 1.0, -1, 0);
+    hipLaunchKernelGGL(k_scale, grid, dim3(TTN_STREAM_TB), 0, g_stream, src->dev(), dst->dev(), 1.0, -1, 0, (const int*)nullptr);
     HIPCHK(hipGetLastError());
     dst->bound = src->bound;
     dst->ot = src->ot;
@@ -548,6 +545,32 @@ int ttn_add(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z) {
     return TTN_OK;
 }
 
+// The core scalar multiplication scales: the first one with ot == 0, else the first (tt_operations.jl:262).  Uniform over the batch
+// -> `which`; trains with different gauge flags (uploaded one by one, or zeroed by ttn_scale_batch) -> a per-train device table.
+static int scaled_core(ttn_tt_t x, int& which, const int*& which_b) {
+    static int* d_which = nullptr; static int which_cap = 0;
+    static std::vector<int> h_which;                     // must outlive the async upload
+    const int d = x->d;
+    h_which.assign(x->batch, 0);
+    bool uniform = true;
+    for (int b = 0; b < x->batch; ++b) {
+        for (int k = 0; k < d; ++k) if (x->ot[(size_t)b * d + k] == 0) { h_which[b] = k; break; }
+        uniform = uniform && h_which[b] == h_which[0];
+    }
+    which = h_which[0];
+    which_b = nullptr;
+    if (uniform) return TTN_OK;
+    if (which_cap < x->batch) {
+        if (d_which) { HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipFree(d_which)); d_which = nullptr; }
+        HIPCHK(hipMalloc((void**)&d_which, sizeof(int) * x->batch));
+        which_cap = x->batch;
+    }
+    HIPCHK(hipMemcpyAsync(d_which, h_which.data(), sizeof(int) * x->batch, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));              // h_which is reused by the next call
+    which_b = d_which;
+    return TTN_OK;
+}
+
 int ttn_scale(double a, ttn_tt_t x, ttn_tt_t y) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     NEED_INIT();
@@ -555,13 +578,14 @@ int ttn_scale(double a, ttn_tt_t x, ttn_tt_t y) {
     if (!same_dims(x->dims, y->dims) || x->batch != y->batch) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
     const int d = x->d;
     for (int m = 0; m <= d; ++m) if (y->cap[m] < x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_scale: destination capacity too small");
-    // i = findfirst(==(0), ot), else 1  (tt_operations.jl:262); all trains of a batch share ot by construction
+    // i = findfirst(==(0), ot), else 1  (tt_operations.jl:262), per train
     int which = 0;
-    for (int k = 0; k < d; ++k) if (x->ot[k] == 0) { which = k; break; }
+    const int* which_b = nullptr;
+    { int rc_ = scaled_core(x, which, which_b); if (rc_) return rc_; }
     long long maxsz = 0;
     for (int k = 0; k < d; ++k) maxsz = std::max<long long>(maxsz, (long long)x->dims[k] * x->bound[k] * x->bound[k + 1]);
     if (x != y) hipLaunchKernelGGL(k_ranks_copy, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), x->dev());
-    hipLaunchKernelGGL(k_scale, stream_grid(maxsz, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), a, which, a == 0.0 ? 1 : 0);
+    hipLaunchKernelGGL(k_scale, stream_grid(maxsz, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), a, which, a == 0.0 ? 1 : 0, which_b);
     HIPCHK(hipGetLastError());
     y->bound = x->bound;
     if (a == 0.0) std::fill(y->ot.begin(), y->ot.end(), 0); else y->ot = x->ot;
@@ -579,11 +603,12 @@ int ttn_scale_batch(const double* a, ttn_tt_t x, ttn_tt_t y) {
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(g_dout, a, sizeof(double) * x->batch, hipMemcpyHostToDevice, g_stream));
     int which = 0;
-    for (int k = 0; k < d; ++k) if (x->ot[k] == 0) { which = k; break; }
+    const int* which_b = nullptr;
+    { int rc_ = scaled_core(x, which, which_b); if (rc_) return rc_; }
     long long maxsz = 0;
     for (int k = 0; k < d; ++k) maxsz = std::max<long long>(maxsz, (long long)x->dims[k] * x->bound[k] * x->bound[k + 1]);
     if (x != y) hipLaunchKernelGGL(k_ranks_copy, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), x->dev());
-    hipLaunchKernelGGL(k_scale_batch, stream_grid(maxsz, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), (const double*)g_dout, which);
+    hipLaunchKernelGGL(k_scale_batch, stream_grid(maxsz, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), (const double*)g_dout, which, which_b);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g_stream));      // `a` is caller memory and g_dout is reused by ttn_dot
     y->bound = x->bound;
@@ -633,20 +658,31 @@ int ttn_compress_rank_bound(int64_t d, const int64_t* dims, const int64_t* rks, 
     return TTN_OK;
 }
 
+// Everything that can refuse a compress launch — capacity of the handle for the ranks the sweep can reach from `bound`, the size
+// limits of the merged matrices, the scratch allocation — checked WITHOUT touching the handle (ttn_apply_compress runs this on the
+// product's ranks before it overwrites y's).
+static int compress_precheck(ttn_tt_t psi, const std::vector<int64_t>& bound, int64_t k_single, int64_t max_bond, int64_t sweeps,
+                             int64_t k_first, int64_t k_last, std::vector<int64_t>& fin, long long& pmax, long long& qmax, long long& per_train) {
+    const int d = psi->d;
+    std::vector<int64_t> need;
+    pmax = 1; qmax = 1;
+    rank_bounds(d, psi->dims.data(), bound.data(), max_bond, sweeps, k_single, need, fin, pmax, qmax, k_first, k_last);
+    for (int m = 0; m <= d; ++m)
+        if (need[m] > psi->cap[m]) return fail(TTN_ERR_CAPACITY, "ttn_compress: a bond rank can grow beyond the handle's capacity (see ttn_compress_rank_bound)");
+    if (pmax > 4096 || qmax > 16384) return fail(TTN_ERR_UNSUPPORTED, "ttn_compress: merged matrix larger than 4096 x 16384");
+    per_train = 2 * pmax * qmax + QR_NB * qmax + pmax * QR_NB + 2 * pmax * pmax + 4 * pmax + 64 + 6 * 128 * 128;
+    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * psi->batch);
+    if (rc) return rc;
+    return ensure_batch_bufs(psi->batch);
+}
+
 static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, double truncerr, int64_t sweeps,
                            int64_t k_first = 0, int64_t k_last = 0, ttn_tto_t fuseA = nullptr, ttn_tt_t fusex = nullptr) {
     const int d = psi->d;
     if (d < 2 && k_single == 0) return TTN_OK;
-    std::vector<int64_t> need, fin;
-    long long pmax = 1, qmax = 1;
-    rank_bounds(d, psi->dims.data(), psi->bound.data(), max_bond, sweeps, k_single, need, fin, pmax, qmax, k_first, k_last);
-    for (int m = 0; m <= d; ++m)
-        if (need[m] > psi->cap[m]) return fail(TTN_ERR_CAPACITY, "ttn_compress: a bond rank can grow beyond the handle's capacity (see ttn_compress_rank_bound)");
-    if (pmax > 4096 || qmax > 16384) return fail(TTN_ERR_UNSUPPORTED, "ttn_compress: merged matrix larger than 4096 x 16384");
-    const long long per_train = 2 * pmax * qmax + QR_NB * qmax + pmax * QR_NB + 2 * pmax * pmax + 4 * pmax + 64 + 6 * 128 * 128;
-    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * psi->batch);
-    if (rc) return rc;
-    rc = ensure_batch_bufs(psi->batch);
+    std::vector<int64_t> fin;
+    long long pmax = 1, qmax = 1, per_train = 0;
+    int rc = compress_precheck(psi, psi->bound, k_single, max_bond, sweeps, k_first, k_last, fin, pmax, qmax, per_train);
     if (rc) return rc;
     const int steps = k_single > 0 ? 1 : (k_single < 0 ? (int)(std::llabs(k_last - k_first) + 1) : (int)(2 * (d - 1) * sweeps));
     if (psi->sv_on) {
@@ -669,8 +705,8 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     P.pmax = (int)pmax; P.qmax = (int)qmax;
     P.sv_out = psi->sv_on ? psi->d_sv : nullptr;
     P.sv_steps = steps;
-    P.status = g_status;
-    P.sweep_stats = g_status + psi->batch;
+    P.status = psi->d_status;
+    P.sweep_stats = psi->d_status + psi->batch;
     P.rank_rule = 0;
     P.fused = (fuseA && fusex) ? 1 : 0;
     if (P.fused) { P.op = fuseA->dev(); P.x = fusex->dev(); }
@@ -778,9 +814,14 @@ int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, do
     if (x == y) return fail(TTN_ERR_ARG, "ttn_apply_compress: output must not alias the input");
     const int d = x->d;
     for (int m = 0; m <= d; ++m) if (y->cap[m] < A->rks[m] * x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_apply: destination capacity too small");
+    // every check that can refuse the launch runs on the product's ranks BEFORE y is touched: on an error return y still holds
+    // what it held (ranks, bounds, gauge flags and cores)
+    std::vector<int64_t> yb(d + 1), fin_;
+    for (int m = 0; m <= d; ++m) yb[m] = A->rks[m] * x->bound[m];
+    { long long pm_, qm_, pt_; int rc = compress_precheck(y, yb, 0, max_bond, sweeps, 0, 0, fin_, pm_, qm_, pt_); if (rc) return rc; }
     hipLaunchKernelGGL(k_ranks_mul_op, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), A->dev(), x->dev());
     HIPCHK(hipGetLastError());
-    for (int m = 0; m <= d; ++m) y->bound[m] = A->rks[m] * x->bound[m];
+    y->bound = yb;
     std::fill(y->ot.begin(), y->ot.end(), 0);
     return launch_compress(y, 0, max_bond, truncerr, sweeps, 0, 0, A, x);
 }
@@ -821,8 +862,8 @@ static int launch_chain(int kind, ttn_tt_t x, ttn_tt_t y, ttn_tt_t z, int n, int
     P.scratch_stride = per_train;
     P.pmax = (int)pmax; P.qmax = (int)qmax;
     P.sv_out = nullptr; P.sv_steps = 0;
-    P.status = g_status;
-    P.sweep_stats = g_status + batch;
+    P.status = z->d_status;                 // the handle the chain writes (kind 2: in place on z)
+    P.sweep_stats = z->d_status + batch;
     P.prof = nullptr;
     { const char* e = getenv("TTN_JTOL"); P.jtol_mult = e ? atof(e) : 1.0; }
     { const char* e = getenv("TTN_JNEG"); P.jneg_mult = e ? atof(e) : 1.0; }
@@ -958,8 +999,8 @@ int ttn_ttv_decomp(ttn_tt_t z, const double* tensors, int64_t index, double tol)
     P.scratch = base + 3 * total;                          // per train: [cur0 | cur1 | M2 | LQ / Jacobi scratch]
     P.scratch_stride = per_train;
     P.pmax = (int)pmax; P.qmax = (int)qmax;
-    P.status = g_status;
-    P.sweep_stats = g_status + batch;
+    P.status = z->d_status;
+    P.sweep_stats = z->d_status + batch;
     { const char* e = getenv("TTN_JTOL"); P.jtol_mult = e ? atof(e) : 1.0; }
     { const char* e = getenv("TTN_JNEG"); P.jneg_mult = e ? atof(e) : 1.0; }
     H.tensors = d_in;
@@ -1046,7 +1087,7 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
     P.off = d_tab;
     P.rfix = d_tab + 4 * d;
     P.mmax = (int)mmax; P.rmax = (int)rmax;
-    P.status = g_status;
+    P.status = x->d_status;
     hipLaunchKernelGGL(k_als_linsolve, dim3(batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, P);
     HIPCHK(hipGetLastError());
     // orthogonality flags as the core moves leave them (als.jl:128-134, :112-118)
@@ -1130,9 +1171,9 @@ static int two_site_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, d
     P.A = A->dev(); P.b = b->dev(); P.x = x->dev();
     P.scratch = base; P.scratch_stride = per_train;
     P.off = d_tab;
-    P.status = g_status;
-    Q.C.status = g_status;
-    Q.C.sweep_stats = g_status + batch;
+    P.status = x->d_status;
+    Q.C.status = x->d_status;
+    Q.C.sweep_stats = x->d_status + batch;
     Q.C.pmax = (int)pmax; Q.C.qmax = (int)qmax;
     { const char* e = getenv("TTN_JTOL"); Q.C.jtol_mult = e ? atof(e) : 1.0; }
     { const char* e = getenv("TTN_JNEG"); Q.C.jneg_mult = e ? atof(e) : 1.0; }
@@ -1179,10 +1220,14 @@ int ttn_dmrg_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double t
     return two_site_linsolve(A, b, x0, x, tol, rmax_schedule[n_stages - 1], 1, plan);
 }
 
-// status of the last dense kernel (synchronises): returns TTN_ERR_NO_CONVERGENCE if any train failed
-static int check_status(int batch) {
+// Failure codes of every dense kernel that wrote `h` since the last call (synchronises).  The codes are sticky on the device —
+// a kernel only ever stores a non-zero code, so a failure inside a chain of launches survives the launches after it — and
+// are cleared here, on read.
+static int check_status(ttn_tt_t h) {
+    const int batch = h->batch;
     std::vector<int> st(batch);
-    HIPCHK(hipMemcpyAsync(st.data(), g_status, sizeof(int) * batch, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(st.data(), h->d_status, sizeof(int) * batch, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemsetAsync(h->d_status, 0, sizeof(int) * batch, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     for (int b = 0; b < batch; ++b) if (st[b] == 3) return fail(TTN_ERR_SINGULAR, "als_linsolve: a local system K is singular");
     for (int b = 0; b < batch; ++b) if (st[b] == 4) return fail(TTN_ERR_DIMS, "als_linsolve: a train's ranks differ from the ranks of the start handle");
@@ -1195,14 +1240,13 @@ int ttn_compress_status(ttn_tt_t psi, int64_t* total_jacobi_sweeps) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     NEED_INIT();
     if (!psi) return fail(TTN_ERR_ARG, "null handle");
-    if (psi->batch > g_status_cap) return fail(TTN_ERR_ARG, "no dense kernel has run for this batch size");
     if (total_jacobi_sweeps) {
         std::vector<int> st(psi->batch);
-        HIPCHK(hipMemcpyAsync(st.data(), g_status + psi->batch, sizeof(int) * psi->batch, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipMemcpyAsync(st.data(), psi->d_status + psi->batch, sizeof(int) * psi->batch, hipMemcpyDeviceToHost, g_stream));
         HIPCHK(hipStreamSynchronize(g_stream));
         for (int b = 0; b < psi->batch; ++b) total_jacobi_sweeps[b] = st[b];
     }
-    return check_status(psi->batch);
+    return check_status(psi);
 }
 
 // diagnostic: per-phase cycle counters (100 MHz s_memtime ticks) of train b from the last TTN_PROF=1 compress launch

@@ -37,8 +37,19 @@
 //  * the MFMA fragment reads take two k-rows per 32-lane half (ds_read_b64, 64 banks): LD*8 mod 256 = 136 puts the second
 //    row 2 banks short of the other half: one 2-way conflict per read instead of none.
 #define GEMM_LD 145
-#define GEMM_LDS_DOUBLES (128 * 128 + 512)         // LDS region every GEMM may use (the one-shot small GEMM uses all of it): the 128x128
-                                                   // Jacobi image + room for the odd leading dimensions of a 64x64x128 one-shot product
+// The LDS IMAGE region (Jacobi / Cholesky / eigensolver images with leading dimension 128, LQ images, staged GEMM operands):
+//   1024-thread build: 128 x 128 doubles, one workgroup per CU (its 16 waves at 128 VGPRs fill the register file anyway);
+//   512-thread build:   64 x 128 doubles — the whole kernel then needs < 80 KB of LDS and TWO workgroups share a CU (8 waves at 128
+//   VGPRs each), so the serial phases of one train (reflectors, pivots, bisection rounds, barriers) overlap the other's work.
+//   Images of more than TTN_LDS_COLS columns take the blocked / global-memory forms there.
+#if TTN_WG == 512
+#define TTN_LDS_IMG (64 * 128)
+#else
+#define TTN_LDS_IMG (128 * 128)
+#endif
+#define TTN_LDS_COLS (TTN_LDS_IMG / 128)           // columns of a leading-dimension-128 image
+#define GEMM_LDS_DOUBLES (TTN_LDS_IMG + 512)       // LDS region every GEMM may use (the one-shot small GEMM uses all of it): the
+                                                   // image + room for the odd leading dimensions of a 64x64x128 one-shot product
 // Call-boundary policy of the big building blocks (experiments: -DTTN_NI_JACOBI=inline etc.)
 #ifndef TTN_NI_JACOBI
 #define TTN_NI_JACOBI __noinline__
@@ -156,8 +167,16 @@ struct GemmDesc {
 // Behind the LDS tiles: the descriptor (sizeof(GemmDesc) = 208 bytes, 32 doubles reserved) and the OFFSET TABLES.
 // Operands are 2-level strided Views, so an element address costs two integer divisions; a GEMM evaluates ix() once per
 // row / column / k index into these tables and the staging loops only add table entries.
+// (32-bit entries, two per double of the region: element offsets fit 32 bits, operands are at most 4096 x 16384 doubles)
+#if TTN_WG == 512
+#define GEMM_TAB_ENTRIES 704                     // doubles: tiled 2 x GEMM_KSLAB + BM + BN ints; one-shot 4 x 128 + 2 x 256 ints
+#define GEMM_KSLAB 512
+#define GEMM_SMALL_KMAX 256
+#else
 #define GEMM_TAB_ENTRIES 1536
-#define GEMM_KSLAB (GEMM_TAB_ENTRIES / 2)        // k indices tabulated at a time by the tiled GEMM (A and B tables)
+#define GEMM_KSLAB 768                           // k indices tabulated at a time by the tiled GEMM (A and B tables)
+#define GEMM_SMALL_KMAX 512                      // one-shot GEMM: k <= GEMM_LDS_DOUBLES / 34
+#endif
 #define GEMM_DESC_DOUBLES (32 + GEMM_TAB_ENTRIES)
 #define GEMM_LDS_TOTAL (GEMM_LDS_DOUBLES + GEMM_DESC_DOUBLES)
 typedef __attribute__((address_space(3))) long long lds_i64;
@@ -206,7 +225,7 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc_, double* lds) {
     const lds_gdesc* dsc = (const lds_gdesc*)dsc_;
     constexpr int WCN = TTN_NWAVES / WR;                 // wave columns
     constexpr int BM = 32 * WR, BN = 32 * WCN;
-    constexpr int LDA = GEMM_LD, LDB = (BN <= 128) ? GEMM_LD : 273;     // both == 17 mod 32 (see GEMM_LD)
+    constexpr int LDA = (BM <= 64) ? 81 : GEMM_LD, LDB = (BN <= 64) ? 81 : (BN <= 128) ? GEMM_LD : 273;     // all == 17 mod 32 (see GEMM_LD)
     constexpr int STAGE = GEMM_BK * (LDA + LDB);
     static_assert(2 * STAGE <= GEMM_LDS_DOUBLES, "two LDS stages must fit");
     const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
@@ -398,42 +417,42 @@ __device__ TTN_NI_GEMMS void wg_gemm_small_impl(const GemmDesc* dsc_, double* ld
     // ---- offset tables (m, n <= 128; k <= 512 because k*(lda+ldb) <= GEMM_LDS_DOUBLES and lda, ldb >= 16) ----
     gmem_f64* Ag = (gmem_f64*)A.p;
     gmem_f64* Bg = (gmem_f64*)B.p;
-    lds_i64* rowA = (lds_i64*)(lds + GEMM_LDS_DOUBLES + 32);
-    lds_i64* colB = rowA + 128;
-    lds_i64* rowC = colB + 128;
-    lds_i64* colC = rowC + 128;
-    lds_i64* kA = colC + 128;
-    lds_i64* kB = kA + 512;
+    lds_i32* rowA = (lds_i32*)(lds + GEMM_LDS_DOUBLES + 32);
+    lds_i32* colB = rowA + 128;
+    lds_i32* rowC = colB + 128;
+    lds_i32* colC = rowC + 128;
+    lds_i32* kA = colC + 128;
+    lds_i32* kB = kA + GEMM_SMALL_KMAX;
     for (int i = tid; i < 128; i += TTN_WG) {
-        rowA[i] = (i < m) ? ix(A.r, i) : 0;
-        rowC[i] = (i < m) ? ix(C.r, i) : 0;
-        colB[i] = (i < n) ? ix(B.c, i) : 0;
-        colC[i] = (i < n) ? ix(C.c, i) : 0;
+        rowA[i] = (i < m) ? (int)ix(A.r, i) : 0;
+        rowC[i] = (i < m) ? (int)ix(C.r, i) : 0;
+        colB[i] = (i < n) ? (int)ix(B.c, i) : 0;
+        colC[i] = (i < n) ? (int)ix(C.c, i) : 0;
     }
-    for (int i = tid; i < k; i += TTN_WG) { kA[i] = ix(A.c, i); kB[i] = ix(B.r, i); }
+    for (int i = tid; i < k; i += TTN_WG) { kA[i] = (int)ix(A.c, i); kB[i] = (int)ix(B.r, i); }
     __syncthreads();
     // ---- stage all of A (m x k) and B (k x n), zero padding rows/cols up to the tile edge; 16 lanes walk the
     //      operand's fast (small-stride) index, the 64 lane groups its slow index: no divisions in the loops ----
     const int fx = tid & 15, sy = tid >> 4;
     if (a_kfast) {
         for (int r = sy; r < mp; r += TTN_WG / 16) {
-            const long long ro = rowA[r];
+            const int ro = rowA[r];
             for (int kk = fx; kk < k; kk += 16) As[kk * lda + r] = (r < m) ? Ag[ro + kA[kk]] : 0.0;
         }
     } else {
         for (int kk = sy; kk < k; kk += TTN_WG / 16) {
-            const long long ko = kA[kk];
+            const int ko = kA[kk];
             for (int r = fx; r < mp; r += 16) As[kk * lda + r] = (r < m) ? Ag[rowA[r] + ko] : 0.0;
         }
     }
     if (b_kfast) {
         for (int c = sy; c < np; c += TTN_WG / 16) {
-            const long long co = colB[c];
+            const int co = colB[c];
             for (int kk = fx; kk < k; kk += 16) Bs[kk * ldb + c] = (c < n) ? Bg[co + kB[kk]] : 0.0;
         }
     } else {
         for (int kk = sy; kk < k; kk += TTN_WG / 16) {
-            const long long ko = kB[kk];
+            const int ko = kB[kk];
             for (int c = fx; c < np; c += 16) Bs[kk * ldb + c] = (c < n) ? Bg[colB[c] + ko] : 0.0;
         }
     }
@@ -464,7 +483,7 @@ __device__ TTN_NI_GEMMS void wg_gemm_small_impl(const GemmDesc* dsc_, double* ld
         for (int reg = 0; reg < 4; ++reg) {
             const int gi = r0 + lk + 4 * reg, gj = c0 + li;
             if (gi < m && gj < n) {
-                gmem_wf64* cp = (gmem_wf64*)C.p + rowC[gi] + colC[gj];
+                gmem_wf64* cp = (gmem_wf64*)C.p + ((long long)rowC[gi] + colC[gj]);
                 double v = alpha * acc[reg];
                 if (beta != 0.0) v += beta * (*cp);
                 *cp = v;
@@ -1114,7 +1133,7 @@ template <int NT2, int LD>
 __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* flag, double* red,
                                   double tol_mult, double neg_mult, double* aneg_out, int max_sweeps = JACOBI_MAX_SWEEPS,
                                   bool cross_only = false, double aneg_fixed = -1.0) {
-    constexpr int CMASK = (128 * 128) / LD - 1;         // columns the LDS image holds, minus one
+    constexpr int CMASK = TTN_LDS_IMG / LD - 1;         // columns the LDS image holds, minus one
     constexpr int G = 4;                                // lane groups per wave = columns per block
     constexpr int CH = 32;                              // doubles per 16-byte-per-lane piece of a column
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
@@ -1220,7 +1239,7 @@ __device__ int jacobi_lds128_body(int m, int p, lds_f64* X, lds_f64* nrm2, int* 
         }
         __syncthreads();
         // ---- levels ----
-        constexpr int PPW = (16 + TTN_NWAVES - 1) / TTN_NWAVES;         // block pairs a wave owns per block round (p <= 128)
+        constexpr int PPW = ((CMASK + 1) / 8 + TTN_NWAVES - 1) / TTN_NWAVES;   // block pairs a wave owns per block round (image full)
         for (int gs = nbp; gs >= (cross_only ? nbp : 2); gs >>= 1) {
             const int h = gs >> 1;
             int gam[PPW], aa[PPW], ci[PPW];
@@ -1342,23 +1361,27 @@ __device__ TTN_NI_JACOBI int wg_jacobi_lds128(int m, int p, double* Xg, double* 
 //   (coalesced); a visit that rotated nothing is not written back.  Converged when a whole sweep rotates nothing.
 // Replaces the global-memory Jacobi (wg_jacobi_cols, 3-4x slower at these sizes), which remains the fallback for p > 256.
 // -------------------------------------------------------------------------------------------------
-#define JB_W 32
+// LD = leading dimension of the LDS image (>= m), JBW = columns per block: 2 * JBW * LD doubles of image.
+template <int LD, int JBW>
 __device__ inline void jb_load(lds_f64* X, int col0_lds, const double* Xg, int ldx, int c0, int ncols, int m) {
-    // columns c0 .. c0+ncols-1 of Xg -> LDS columns col0_lds .., rows >= m and missing columns zero-filled (32 columns always)
-    for (int e = threadIdx.x; e < JB_W * 256; e += TTN_WG) {
-        const int r = e & 255, c = e >> 8;
-        X[(col0_lds + c) * 256 + r] = (c < ncols && r < m) ? Xg[(long long)(c0 + c) * ldx + r] : 0.0;
+    // columns c0 .. c0+ncols-1 of Xg -> LDS columns col0_lds .., rows >= m and missing columns zero-filled (JBW columns always)
+    for (int e = threadIdx.x; e < JBW * LD; e += TTN_WG) {
+        const int r = e % LD, c = e / LD;
+        X[(col0_lds + c) * LD + r] = (c < ncols && r < m) ? Xg[(long long)(c0 + c) * ldx + r] : 0.0;
     }
 }
+template <int LD, int JBW>
 __device__ inline void jb_store(const lds_f64* X, int col0_lds, double* Xg, int ldx, int c0, int ncols, int m) {
-    for (int e = threadIdx.x; e < JB_W * 256; e += TTN_WG) {
-        const int r = e & 255, c = e >> 8;
-        if (c < ncols && r < m) Xg[(long long)(c0 + c) * ldx + r] = X[(col0_lds + c) * 256 + r];
+    for (int e = threadIdx.x; e < JBW * LD; e += TTN_WG) {
+        const int r = e % LD, c = e / LD;
+        if (c < ncols && r < m) Xg[(long long)(c0 + c) * ldx + r] = X[(col0_lds + c) * LD + r];
     }
 }
 
-__device__ __noinline__ int wg_jacobi_blocked256(int m, int p, double* Xg, int ldx, double* Xlds, double* nrm2g, int* flag, double* red,
-                                                 double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
+template <int LD, int JBW>
+__device__ int jacobi_blocked_body(int m, int p, double* Xg, int ldx, double* Xlds, double* nrm2g, int* flag, double* red,
+                                   double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
+    static_assert(2 * JBW * LD <= TTN_LDS_IMG, "two column blocks must fit the LDS image");
     m = uni32(m); p = uni32(p); ldx = uni32(ldx);
     Xg = unip(Xg); Xlds = unip(Xlds); nrm2g = unip(nrm2g); flag = unip(flag); red = unip(red); aneg_out = unip(aneg_out);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = TTN_WG >> 6;
@@ -1375,29 +1398,29 @@ __device__ __noinline__ int wg_jacobi_blocked256(int m, int p, double* Xg, int l
     const double aneg = neg_mult * neg_mult * (double)m * DBL_EPSILON * DBL_EPSILON * amax;
     if (tid == 0) *aneg_out = aneg;
     __syncthreads();
-    const int nbk = (p + JB_W - 1) / JB_W;
+    const int nbk = (p + JBW - 1) / JBW;
     for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
         int any = 0;
         for (int I = 0; I < nbk; ++I) {                                           // (a) inside every block
-            const int nI = min(JB_W, p - I * JB_W);
+            const int nI = min(JBW, p - I * JBW);
             __syncthreads();
-            jb_load(X, 0, Xg, ldx, I * JB_W, nI, m);
+            jb_load<LD, JBW>(X, 0, Xg, ldx, I * JBW, nI, m);
             __syncthreads();
-            const int r = jacobi_lds128_body<8, 256>(m, nI, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out, 1, false, aneg);
-            if (r < 0) { any = 1; jb_store(X, 0, Xg, ldx, I * JB_W, nI, m); }
+            const int r = jacobi_lds128_body<LD / 32, LD>(m, nI, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out, 1, false, aneg);
+            if (r < 0) { any = 1; jb_store<LD, JBW>(X, 0, Xg, ldx, I * JBW, nI, m); }
         }
         for (int I = 0; I + 1 < nbk; ++I)                                          // (b) between every two blocks
             for (int J = I + 1; J < nbk; ++J) {
-                const int nJ = min(JB_W, p - J * JB_W);
+                const int nJ = min(JBW, p - J * JBW);
                 __syncthreads();
-                jb_load(X, 0, Xg, ldx, I * JB_W, JB_W, m);
-                jb_load(X, JB_W, Xg, ldx, J * JB_W, nJ, m);
+                jb_load<LD, JBW>(X, 0, Xg, ldx, I * JBW, JBW, m);
+                jb_load<LD, JBW>(X, JBW, Xg, ldx, J * JBW, nJ, m);
                 __syncthreads();
-                const int r = jacobi_lds128_body<8, 256>(m, JB_W + nJ, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out, 1, true, aneg);
+                const int r = jacobi_lds128_body<LD / 32, LD>(m, JBW + nJ, X, nrm2, flag, red, tol_mult, neg_mult, aneg_out, 1, true, aneg);
                 if (r < 0) {
                     any = 1;
-                    jb_store(X, 0, Xg, ldx, I * JB_W, JB_W, m);
-                    jb_store(X, JB_W, Xg, ldx, J * JB_W, nJ, m);
+                    jb_store<LD, JBW>(X, 0, Xg, ldx, I * JBW, JBW, m);
+                    jb_store<LD, JBW>(X, JBW, Xg, ldx, J * JBW, nJ, m);
                 }
             }
         __syncthreads();
@@ -1405,6 +1428,18 @@ __device__ __noinline__ int wg_jacobi_blocked256(int m, int p, double* Xg, int l
     }
     return -JACOBI_MAX_SWEEPS;
 }
+// 128 < p <= 256 (ranks 65..128): image leading dimension 256, as many columns per block as two blocks fit the image
+__device__ __noinline__ int wg_jacobi_blocked256(int m, int p, double* Xg, int ldx, double* Xlds, double* nrm2g, int* flag, double* red,
+                                                 double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
+    return jacobi_blocked_body<256, TTN_LDS_IMG / 512>(m, p, Xg, ldx, Xlds, nrm2g, flag, red, tol_mult, neg_mult, aneg_out);
+}
+#if TTN_LDS_COLS < 128
+// TTN_LDS_COLS < p <= 128 in the small-image build: the same blocked scheme with leading dimension 128
+__device__ __noinline__ int wg_jacobi_blocked128(int m, int p, double* Xg, int ldx, double* Xlds, double* nrm2g, int* flag, double* red,
+                                                 double tol_mult, double neg_mult, double* aneg_out /*LDS*/) {
+    return jacobi_blocked_body<128, TTN_LDS_IMG / 256>(m, p, Xg, ldx, Xlds, nrm2g, flag, red, tol_mult, neg_mult, aneg_out);
+}
+#endif
 
 // -------------------------------------------------------------------------------------------------
 // Cholesky G = L L^T in LDS (column-major, leading dimension 128, n <= 128), in place: on exit the lower
@@ -1429,7 +1464,7 @@ __device__ int chol_lds128_teams(int n, double* Gg, double* red, int* flag, doub
     const int team = (threadIdx.x >> 6) / WPT, wave = (threadIdx.x >> 6) % WPT, nwaves = WPT;
     const int tid = threadIdx.x - team * WPT * 64;       // thread index inside the team
     const int li = lane & 15, lk = lane >> 4;
-    lds_f64* G = (lds_f64*)Gg + team * 64 * 128;
+    lds_f64* G = (lds_f64*)Gg + team * (TTN_LDS_IMG / 2);
     lds_f64* invd = (lds_f64*)red + 32 * team;           // 1 / l_kk of the current panel ([0..15]) and the column buffer ([16..31])
     double dmax = 0.0;
     if (wave == 0) {
@@ -1542,7 +1577,7 @@ __device__ int chol_lds128_teams(int n, double* Gg, double* red, int* flag, doub
 __device__ TTN_NI_CHOL int wg_chol_lds128(int n, double* Gg, double* red, int* flag, double* pivmin_out /*LDS*/) {
     return chol_lds128_teams<1>(n, Gg, red, flag, pivmin_out);
 }
-// two n x n matrices (n <= 64) at Gg and Gg + 64*128; red: 64 doubles; pivmin_out: 2 doubles
+// two n x n matrices (n <= TTN_LDS_COLS / 2) at Gg and Gg + TTN_LDS_IMG / 2; red: 64 doubles; pivmin_out: 2 doubles
 __device__ TTN_NI_CHOL int wg_chol2_lds128(int n, double* Gg, double* red64, int* flag, double* pivmin_out2 /*LDS*/) {
     return chol_lds128_teams<2>(n, Gg, red64, flag, pivmin_out2);
 }
@@ -1578,12 +1613,16 @@ struct CompressArgs {
     TTDev x;
     int rank_rule;         // 0: relative tail norm (_svdtrunc, tt_cross_interpolation.jl:149-166); 1: count(s > truncerr * s[1]), at least 1
                            //    (_swap_adjacent_sites, src/qtt_tools.jl:680-685)
+    int* next_train;       // null: one workgroup per train (grid = batch).  Else a device counter (zeroed before the launch): the grid is
+                           // PERSISTENT — workgroup w starts with train w and then pulls train gridDim.x + atomicAdd(next_train, 1)
+                           // until the batch is exhausted (dynamic balancing of the data-dependent sweep counts, scratch per slot)
 };
 
 #define COMPRESS_LDS_X_DOUBLES (128 * 128)
 #define COMPRESS_LDS_BYTES ((GEMM_LDS_TOTAL + 32 + 2 * QR_NB * QR_NB + QR_NB + 8 + 8 + 128) * sizeof(double))
 #define FAST_KAPPA_MAX 128.0          // fast paths are used only when sigma_max/sigma_min <= this (error ~ eps*kappa^2)
 #define FAST_KAPPA_POLISH 32768.0     // Gram route with a Jacobi polish of U^T M up to this conditioning of the kept block
+#define FAST_POLISH_DROP 1.0e-12      // ... and only if the singular values it drops carry at most this share of ||M||_F^2 (i.e. are noise)
 #define FAST_DIAG_TOL 2.0e-12         // route F: A'^T A' counts as diagonal below this (relative to sqrt(G_ii G_jj))
 #define FAST_CHECK_TOL 2.0e-11        // a-posteriori bound on |Rf Rf^T - Sigma| (and Lf^T Lf - Sigma), relative
 
@@ -1603,6 +1642,9 @@ __device__ int wg_svd_cols(const CompressArgs& P, const BondCtx& S, int pj, doub
     // mlen: column length if it is not pj (LDS image only: the polish step of the Gram route runs r columns of length q)
     const int nsw = (in_lds && mlen) ? wg_jacobi_lds128(mlen, pj, X, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
                   : in_lds ? wg_jacobi_lds128(pj, pj, X, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
+#if TTN_LDS_COLS < 128
+                  : (pj <= 128) ? wg_jacobi_blocked128(pj, pj, X, ldx, S.ldsX, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
+#endif
                   : (pj <= 256) ? wg_jacobi_blocked256(pj, pj, X, ldx, S.ldsX, S.nrm2, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal)
                                 : wg_jacobi_cols(pj, pj, X, ldx, S.iflag, S.red, P.jtol_mult, P.jneg_mult, S.scal);
     for (int c = wave; c < pj; c += nwaves) {
@@ -1807,7 +1849,10 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
     S.scal = S.taus + QR_NB;                              // 8 misc doubles (scal[0] = Jacobi's negligible threshold)
     S.iflag = reinterpret_cast<int*>(S.scal + 8);         // 8 ints
     S.nrm2 = S.scal + 16;                                 // 128 cached squared column norms
-    double* scr = P.scratch + (long long)b * P.scratch_stride;
+    // scratch belongs to the WORKGROUP SLOT, not to the train: a persistent grid (k_compress with a train counter) reuses the slot for
+    // every train the workgroup pulls, so the hot footprint is #slots x per_slot whatever the batch size (every other caller
+    // launches one workgroup per train: blockIdx.x == b there)
+    double* scr = P.scratch + (long long)blockIdx.x * P.scratch_stride;
     const long long pq = (long long)P.pmax * P.qmax;
     S.M = scr;                                            // p x q row-major
     S.M2 = S.M + pq;                                      // copy for LQ (F path: Lf/Rf staging uses M..M2)
@@ -1847,7 +1892,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
     bool done = false;
 
     // =============================== route F: factored ===============================
-    if (SWAP == 0 && P.fast && rm < p && rm <= 128 && rm >= 2) {
+    if (SWAP == 0 && P.fast && rm < p && rm <= TTN_LDS_COLS && rm >= 2) {
         // scales
         double sa = 0.0, sb = 0.0;
         for (long long e = tid; e < (long long)n1 * Dl * rm; e += TTN_WG) sa = fmax(sa, fabs(ck[e]));
@@ -1894,12 +1939,12 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                     S.T3[i + 128 * j] = sqrt(S.Ga[i * 129]) * S.Gb[i + 128 * j] * sqrt(S.Ga[j * 129]);
                 }
                 __syncthreads();
-            } else if (rm <= 64) {
+            } else if (rm <= TTN_LDS_COLS / 2) {
                 // both Cholesky factorisations at once, one per half of the workgroup (wg_chol2_lds128)
-                for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) { S.ldsX[e] = S.Ga[e]; S.ldsX[64 * 128 + e] = S.Gb[e]; }
+                for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) { S.ldsX[e] = S.Ga[e]; S.ldsX[TTN_LDS_IMG / 2 + e] = S.Gb[e]; }
                 __syncthreads();
                 ok = wg_chol2_lds128(rm, S.ldsX, S.Ts, S.iflag, S.scal + 1) == 0;     // Ts: 256 doubles of LDS, free here
-                for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) { S.Ga[e] = S.ldsX[e]; S.Gb[e] = S.ldsX[64 * 128 + e]; }
+                for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) { S.Ga[e] = S.ldsX[e]; S.Gb[e] = S.ldsX[TTN_LDS_IMG / 2 + e]; }
                 __syncthreads();
             } else {
                 // L_A
@@ -2049,17 +2094,21 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         const double inv_s0 = 1.0 / s0;
         PROF_MARK(1)
         const bool need_lq = q > p;
-        const bool x_in_lds = p <= 128;                       // fast Jacobi: X in LDS with leading dimension 128
+        const bool x_in_lds = p <= TTN_LDS_COLS;              // fast Jacobi: X in LDS with leading dimension 128
         double* X = x_in_lds ? S.ldsX : S.Xg;
-        const int ldx = x_in_lds ? 128 : p;
+        int ldx = x_in_lds ? 128 : p;
 
         // small merged matrices (the rank-ramp steps) fit the LDS whole: their Householder LQ needs no GEMM calls and costs
         // about what the Gram + Cholesky do, without the conditioning gamble — route H directly
         const bool lq_in_lds = (long long)p * q <= GEMM_LDS_DOUBLES || GEMM_LDS_DOUBLES / p >= 2 * p;     // whole, or TSQR chunks (wg_lq_blocked)
         const bool eig_ok = SWAP == 0 && P.fast && !(P.fast & 2) && need_lq && ((p > 64 && p <= 128 && P.max_bond <= 64) || (p == 64 && P.max_bond < 64));
-        for (int attempt = (SWAP == 0 && P.fast && need_lq && x_in_lds && p >= 2 && (!lq_in_lds || eig_ok)) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
+        // (the eigensolver leaves its image — at most 64 columns — in LDS whatever p is; the Cholesky + Jacobi form needs the whole L there)
+        for (int attempt = (SWAP == 0 && P.fast && need_lq && (eig_ok || (x_in_lds && !lq_in_lds)) && p >= 2) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
             bool ok = true;
             bool use_eig = false;
+            double gram_trace = 0.0;
+            X = (x_in_lds || attempt == 1) ? S.ldsX : S.Xg;
+            ldx = (x_in_lds || attempt == 1) ? 128 : p;
             if (attempt == 1) {
                 // =========================== route G: L = chol(M M^T) ===========================
                 wg_gemm(p, p, q, Mv, tview(Mv), mkview(S.Ga, plain(1), plain(128)), inv_s0 * inv_s0, 0.0, lds);
@@ -2076,6 +2125,9 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                     }
                     const int r0 = (int)P.max_bond;
                     const int nev = (P.truncerr > 0.0 || (P.sv_out && step < P.sv_steps)) ? p : r0;
+                    // trace of the Gram matrix = sum of ALL squared singular values: the polish branch below needs the weight of
+                    // the part it drops (the solver only computes the kept eigenvalues)
+                    { double t_ = 0.0; for (int i = tid; i < p; i += TTN_WG) t_ += S.Ga[i * 129]; gram_trace = unif64(wg_sum(t_, S.red)); }
                     ok = ((p == 64) ? wg_eig64(S.Ga, 128, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64)
                                     : wg_eig128(S.Ga, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64, nullptr)) == 0;
                     for (int j = tid; j < p; j += TTN_WG) { S.perm[j] = j; if (j >= nev) S.sigs[j] = 0.0; }      // (sigs / perm hold pmax entries)
@@ -2164,8 +2216,19 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                     // singular values and right vectors of M restricted to that subspace to Jacobi accuracy; the left vectors follow as
                     // M v / sigma — one step of subspace iteration, so the product of the two outputs is M projected on the computed
                     // right vectors and the singular values are off by theta^2 / 2 only (<= 5e-11 at FAST_KAPPA_POLISH).
-                    const bool polish = use_eig && SWAP == 0 && !(P.fast & 16) && P.truncerr == 0.0 && q <= 128 && r <= 64 && r >= 2 &&
-                                        (S.sigs[r - 1] * FAST_KAPPA_POLISH >= S.sigs[0]) && (S.sigs[r - 1] * S.sigs[r - 1] > S.scal[0]);
+                    // That bound needs a GAP behind the kept block: the error of the product is theta * sigma_{r+1} / sigma_1, so the
+                    // branch is taken only when what it drops is noise — dropped weight trace(G) - sum of the kept eigenvalues at most
+                    // FAST_POLISH_DROP of the trace (sigma_{r+1} <= 1e-6 sigma_1: relgap = 1, theta <= eps kappa^2 = 1e-7, product
+                    // error <= 1e-13).  The rank-deficient ramp step of a sweep that was just truncated on its other bond is such a
+                    // step (its dropped part is rounding noise); a matrix with a smooth spectrum goes to the Householder route.
+                    bool polish = use_eig && SWAP == 0 && !(P.fast & 16) && P.truncerr == 0.0 && q <= 128 && r <= 64 && r >= 2 &&
+                                  (S.sigs[r - 1] * FAST_KAPPA_POLISH >= S.sigs[0]) && (S.sigs[r - 1] * S.sigs[r - 1] > S.scal[0]);
+                    if (polish) {
+                        double kept = 0.0;
+                        for (int j = tid; j < r; j += TTN_WG) kept = fma(S.sigs[j], S.sigs[j], kept);
+                        kept = unif64(wg_sum(kept, S.red));
+                        polish = (gram_trace - kept) <= FAST_POLISH_DROP * gram_trace;
+                    }
                     if (!polish) continue;
                     const double aneg0 = S.scal[0];
                     for (int e = tid; e < p * r; e += TTN_WG) {
@@ -2278,31 +2341,41 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
 
 __global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {
     extern __shared__ double lds[];
-    const int b = blockIdx.x;
     const int d = P.tt.d;
-    if (threadIdx.x == 0) { P.status[b] = 0; P.sweep_stats[b] = 0; }
-    __syncthreads();
-    if (P.fused) wg_materialize_core(P, b, 0);
     // ONE call site of the (force-inlined) bond step: as an out-of-line function it received its arguments in VGPRs, so
     // every size, view and pointer derived from them was a per-lane value and the step carried a 512-byte stack frame per
     // lane across its ~25 calls.  Inlined here everything uniform sits in SGPRs.
     const int per_sweep = 2 * (d - 1);
     const int nsteps = (P.k_single > 0) ? 1 : (P.k_single < 0) ? ((P.k_first <= P.k_last ? P.k_last - P.k_first : P.k_first - P.k_last) + 1)
                                                                : P.sweeps * per_sweep;
-    for (int step = 0; step < nsteps; ++step) {
-        int k;
-        bool virt = false;
-        if (P.k_single > 0) k = P.k_single - 1;                                  // _tt_bond_truncate!
-        else if (P.k_single < 0) k = (P.k_first <= P.k_last) ? P.k_first + step : P.k_first - step;     // ttn_sweep
-        else {                                                                   // tt_compress!: L->R then R->L per sweep
-            const int i = step % per_sweep;
-            k = (i < d - 1) ? i : per_sweep - 1 - i;
-            virt = P.fused && step < d - 1;                                      // first L->R sweep of the fused op
+    int b = blockIdx.x;
+    while (b < P.tt.batch) {
+        if (threadIdx.x == 0) P.sweep_stats[b] = 0;        // (P.status is sticky: only failures are stored, the host clears on read)
+        __syncthreads();
+        if (P.fused) wg_materialize_core(P, b, 0);
+        for (int step = 0; step < nsteps; ++step) {
+            int k;
+            bool virt = false;
+            if (P.k_single > 0) k = P.k_single - 1;                                  // _tt_bond_truncate!
+            else if (P.k_single < 0) k = (P.k_first <= P.k_last) ? P.k_first + step : P.k_first - step;     // ttn_sweep
+            else {                                                                   // tt_compress!: L->R then R->L per sweep
+                const int i = step % per_sweep;
+                k = (i < d - 1) ? i : per_sweep - 1 - i;
+                virt = P.fused && step < d - 1;                                      // first L->R sweep of the fused op
+            }
+            const long long ts_ = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            wg_bond_step(P, b, k, step, lds, virt);
+            if (P.prof && step < 120 && threadIdx.x == 0)            // bits 12..31 of the step word: kilo-cycles of the step
+                P.prof[(long long)P.tt.batch * 16 + (long long)b * 120 + step] |= ((((long long)__builtin_amdgcn_s_memtime() - ts_) >> 10) & 0xFFFFF) << 12;
         }
-        const long long ts_ = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        wg_bond_step(P, b, k, step, lds, virt);
-        if (P.prof && step < 120 && threadIdx.x == 0)            // bits 12..31 of the step word: kilo-cycles of the step
-            P.prof[(long long)P.tt.batch * 16 + (long long)b * 120 + step] |= ((((long long)__builtin_amdgcn_s_memtime() - ts_) >> 10) & 0xFFFFF) << 12;
+        if (!P.next_train) break;
+        // next train of this slot: one atomic per train, broadcast through LDS (the bond step ends with a barrier, so nobody still
+        // reads the words behind the image)
+        int* nb = reinterpret_cast<int*>(lds + GEMM_LDS_TOTAL);
+        if (threadIdx.x == 0) *nb = (int)gridDim.x + atomicAdd(P.next_train, 1);
+        __syncthreads();
+        b = uni32(*nb);
+        __syncthreads();
     }
 }
 
@@ -2335,7 +2408,7 @@ __global__ void __launch_bounds__(TTN_WG) k_swap_chain(ChainArgs Q) {
     long long* srl = Q.srk + (long long)b * Q.srk_stride;
     long long* srr = srl + ns;
     long long* rword = srr + ns;
-    if (tid == 0) { P.status[b] = 0; P.sweep_stats[b] = 0; }
+    if (tid == 0) P.sweep_stats[b] = 0;
     __syncthreads();
     // ---- set-up ----
     if (Q.kind == 1) {

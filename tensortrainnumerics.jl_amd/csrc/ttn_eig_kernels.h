@@ -29,7 +29,7 @@ __device__ __forceinline__ void fmac_bcast(double& a, double w, double s_) {
 //   [0, 16384)            phase 1: vL, wL, xcol (3 x 128), part (8 x 128)   | phase 3: D+ then D- ([row][lane], 2 x 8192)
 //                         phase 4: partial dot products (2 x 16 x 64), then the output image X (ld 128)
 //   [16384, 16896)        dg, e, lam, beta (4 x 128)
-#define EIG_TAIL (EIG_N * EIG_N)
+#define EIG_TAIL TTN_LDS_IMG
 
 // ---- 1. tridiagonalisation: dg[0..127], e[0..126] (e[k] couples k, k+1), reflectors v_k (rows of Vst, zeros up to k) and beta_k ----
 // Per column k:  v_k, beta_k (reflector of column k below the diagonal);  p = beta A v;  w = p - (beta/2)(p'v) v;  A -= v w' + w v'.
@@ -77,24 +77,29 @@ template <int N>
 __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, double* lds) {
     Gg = unip(Gg); Vst = unip(Vst); lds = unip(lds); ldg = uni32(ldg);
     constexpr bool TWO = (N == 128);                              // wave 0 holds one (N = 64) or two entries of a vector per lane
-    constexpr int NC = N / 16;                                    // 16-column chunks; thread = (row i, chunk c), tid < N * NC
+    // thread = (row i, chunk c of CW columns), tid < N * NC: 16 columns per thread, or 32 when the workgroup has fewer than N*N/16
+    // threads (N = 128 in the 512-thread build: 64 VGPRs of matrix per lane)
+    constexpr int CW = (N * N / 16 > TTN_WG) ? 32 : 16;
+    constexpr int NH = CW / 16;                                   // 16-lane broadcast groups per chunk
+    constexpr int NC = N / CW;
+    static_assert(N * NC <= TTN_WG, "one thread per (row, column chunk)");
     lds_f64* L = (lds_f64*)lds;
     lds_f64 *vbuf0 = L, *vbuf1 = L + 128, *wL = L + 256, *xnext = L + 384, *part = L + 512;      // part: 8 x 128
     lds_f64 *dg = L + EIG_TAIL, *e = dg + 128, *beta = dg + 384;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tid & (N - 1), c = tid / N;
     const bool actv = tid < N * NC;
-    double a[16];
+    double a[CW];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = actv ? Gg[i + (long long)ldg * (16 * c + j)] : 0.0;
+    for (int j = 0; j < CW; ++j) a[j] = actv ? Gg[i + (long long)ldg * (CW * c + j)] : 0.0;
     // prologue: rows 0 and 1 of the matrix; reflector 0
     if (actv && i == 0) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) wL[16 * c + j] = a[j];      // row 0 (wL is free here)
+        for (int j = 0; j < CW; ++j) wL[CW * c + j] = a[j];      // row 0 (wL is free here)
     }
     if (actv && i == 1) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) xnext[16 * c + j] = a[j];
+        for (int j = 0; j < CW; ++j) xnext[CW * c + j] = a[j];
     }
     __syncthreads();
     if (wave == 0) {
@@ -110,15 +115,23 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
         // A wave owns 64 rows of one 16-column chunk.  Once all its columns are <= k (v is zero there and the entries are never read
         // again) or all its rows are <= k (finished rows: their w only feeds dead entries), it has nothing left to do but to keep its
         // partial sums at zero: on average 7 of the 16 waves (N = 128) still work, and the phase is bound by the fp64 multiply-adds.
-        const bool live = actv && (16 * (c + 1) > k + 1) && ((TWO ? 64 * (wave & 1) : 0) + 63 > k);
-        double vreg = 0.0;
+        const bool live = actv && (CW * (c + 1) > k + 1) && ((TWO ? 64 * (wave & 1) : 0) + 63 > k);
+        double vreg[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) vreg[h] = 0.0;
         if (live) {
-            vreg = vL[16 * c + (lane & 15)];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) vreg[h] = vL[CW * c + 16 * h + (lane & 15)];
             double pp = 0.0;
             asm volatile("s_nop 1");
-#define EIG_MV(j) fmac_bcast<j>(pp, vreg, a[j]);
+#define EIG_MV(j) fmac_bcast<j>(pp, vreg[0], a[j]);
             EIG_BCAST16(EIG_MV)
 #undef EIG_MV
+            if constexpr (NH == 2) {
+#define EIG_MV(j) fmac_bcast<j>(pp, vreg[1], a[16 + j]);
+                EIG_BCAST16(EIG_MV)
+#undef EIG_MV
+            }
             part[c * 128 + i] = pp;
         } else if (actv) part[c * 128 + i] = 0.0;
         lds_barrier();
@@ -153,22 +166,29 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
         }
         if (live) {
             // A -= v w' + w v'
-            const double wreg = wL[16 * c + (lane & 15)];
+            double wreg[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) wreg[h] = wL[CW * c + 16 * h + (lane & 15)];
             const double nvi = -vL[i], nwi = -wL[i];
             asm volatile("s_nop 1");
-#define EIG_UP(j) fmac_bcast<j>(a[j], wreg, nvi); fmac_bcast<j>(a[j], vreg, nwi);
+#define EIG_UP(j) fmac_bcast<j>(a[j], wreg[0], nvi); fmac_bcast<j>(a[j], vreg[0], nwi);
             EIG_BCAST16(EIG_UP)
 #undef EIG_UP
+            if constexpr (NH == 2) {
+#define EIG_UP(j) fmac_bcast<j>(a[16 + j], wreg[1], nvi); fmac_bcast<j>(a[16 + j], vreg[1], nwi);
+                EIG_BCAST16(EIG_UP)
+#undef EIG_UP
+            }
             if (i == k + 2) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) xn_w[16 * c + j] = a[j];
+                for (int j = 0; j < CW; ++j) xn_w[CW * c + j] = a[j];
             }
         }
     }
     // the last 2 x 2 block
     __syncthreads();
-    if (actv && i == N - 2 && c == NC - 1) { dg[N - 2] = a[14]; e[N - 2] = a[15]; }
-    if (actv && i == N - 1 && c == NC - 1) { dg[N - 1] = a[15]; }
+    if (actv && i == N - 2 && c == NC - 1) { dg[N - 2] = a[CW - 2]; e[N - 2] = a[CW - 1]; }
+    if (actv && i == N - 1 && c == NC - 1) { dg[N - 1] = a[CW - 1]; }
     __syncthreads();
 }
 
@@ -297,11 +317,25 @@ __device__ void wg_bisect(int nev, double* lds) {
 //         twist index and 1/||z|| per vector in tw[], zn[].  One lane per vector; wave 0 runs the top-down recurrences (D+, then
 //         z above the twist), wave 1 the bottom-up ones (D-, z below the twist) at the same time.  The recurrences are dependent
 //         chains: the operands of 8 steps are fetched from LDS together. ----
+// D- (and the part of z below the twist) lives in LDS behind D+ when both fit the image (2 * N * 64 doubles), otherwise in global
+// memory (`Dmg`, N * 64 doubles: the dead Gram matrix) — [row][lane] there too, so every access is one coalesced 512-byte line,
+// the stores are fire-and-forget and the loads of 8 steps are issued together like the LDS ones.
 template <int N>
-__device__ void wg_twisted(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f64* zn /*LDS 64 + 64 (partial norms)*/) {
+struct EigDm {
+    static constexpr bool IN_LDS = 2 * N * 64 <= TTN_LDS_IMG;
+    typedef __attribute__((address_space(1))) double gdouble;
+    lds_f64* l;
+    gdouble* g;
+    __device__ __forceinline__ double ld(int idx) const { if constexpr (IN_LDS) return l[idx]; else return g[idx]; }
+    __device__ __forceinline__ void st(int idx, double v) const { if constexpr (IN_LDS) l[idx] = v; else g[idx] = v; }
+};
+template <int N>
+__device__ void wg_twisted(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f64* zn /*LDS 64 + 64 (partial norms)*/, double* Dmg) {
     lds_f64* L = (lds_f64*)lds;
     lds_f64 *dg = L + EIG_TAIL, *e = dg + 128, *lam = dg + 256;
-    lds_f64 *Dp = L, *Dm = L + 64 * 128;                       // [row][lane]
+    lds_f64* Dp = L;                                           // [row][lane]
+    EigDm<N> Dm;
+    Dm.l = L + N * 64; Dm.g = (typename EigDm<N>::gdouble*)(unsigned long long)Dmg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (d_i, e_i) pairs in the reflector scalars' slot are not available: the bisection's pair array lives in L[256..512) = Dp rows
     // 4..7, so the chains read dg / e directly in chunks
@@ -334,18 +368,24 @@ __device__ void wg_twisted(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f64*
             for (int t = 7; t >= 0; --t) {
                 q = fma(-(ee[t] * ee[t]), fast_rcp(q), dd[t] - lm);
                 if (fabs(q) < pivmin) q = -pivmin;
-                Dm[(i0 + t) * 64 + lane] = q;
+                Dm.st((i0 + t) * 64 + lane, q);
             }
         }
     }
-    __syncthreads();
+    __syncthreads();                                             // (a workgroup barrier also completes the global stores of D-)
     if (wave < 2) {
         // twist index: argmin |gamma_i|, gamma_i = D+_i + D-_i - (d_i - lam)   (both waves, redundantly: independent iterations)
         double gbest = 1e300;
         int kb = 0;
-        for (int i = 0; i < N; ++i) {
-            const double g = fabs(Dp[i * 64 + lane] + Dm[i * 64 + lane] - (dg[i] - lm));
-            if (g < gbest) { gbest = g; kb = i; }
+        for (int i0 = 0; i0 < N; i0 += 8) {
+            double dm[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) dm[t] = Dm.ld((i0 + t) * 64 + lane);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double g = fabs(Dp[(i0 + t) * 64 + lane] + dm[t] - (dg[i0 + t] - lm));
+                if (g < gbest) { gbest = g; kb = i0 + t; }
+            }
         }
         // z_k = 1; wave 0: upwards with D+, wave 1: downwards with D-; the entries replace the pivots they consumed
         double z = 1.0, nrm = 0.0;
@@ -357,10 +397,29 @@ __device__ void wg_twisted(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f64*
             }
             if (act) { tw[lane] = kb; zn[lane] = nrm; }
         } else {
-            for (int i = kb; i < N - 1; ++i) {
-                z = -(e[i] * fast_rcp(Dm[(i + 1) * 64 + lane])) * z;
-                Dm[(i + 1) * 64 + lane] = z;
-                nrm = fma(z, z, nrm);
+            if constexpr (EigDm<N>::IN_LDS) {
+                for (int i = kb; i < N - 1; ++i) {
+                    z = -(e[i] * fast_rcp(Dm.ld((i + 1) * 64 + lane))) * z;
+                    Dm.st((i + 1) * 64 + lane, z);
+                    nrm = fma(z, z, nrm);
+                }
+            } else {
+                // global D-: the twist index differs per lane, so the chain runs over ALL rows in chunks of 8 with the loads of a
+                // chunk in flight together; rows at or above a lane's twist are left alone
+                for (int i0 = 0; i0 < N - 1; i0 += 8) {
+                    double dm[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) dm[t] = (i0 + t + 1 < N) ? Dm.ld((i0 + t + 1) * 64 + lane) : 1.0;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int i = i0 + t;
+                        if (i >= kb && i < N - 1) {
+                            z = -(e[i] * fast_rcp(dm[t])) * z;
+                            Dm.st((i + 1) * 64 + lane, z);
+                            nrm = fma(z, z, nrm);
+                        }
+                    }
+                }
             }
             if (act) zn[64 + lane] = nrm;
         }
@@ -374,7 +433,9 @@ __device__ void wg_twisted(int r, double* lds, int* tw /*LDS 64 ints*/, lds_f64*
 // Eigen-decomposition of the symmetric positive definite N x N matrix G (global, column-major, leading dimension ldg), N = 128 or
 // 64: the `nev` largest eigenvalues (descending) -> sig[j] = sqrt(lam_j) (global), and the image X (LDS, ld 128):
 // X[j*128 + row] = sqrt(lam_j) * u_j[row] for j < r (r <= 64, r <= nev).  Vst: 128 x 128 doubles of global scratch.
-// Returns 0, or 1 if a wanted eigenvalue is not positive.
+// Returns 0, or 1 if a wanted eigenvalue is not positive.  When the D+ / D- arrays of the twisted factorisations do not both fit
+// the LDS image (N = 128 in the 512-thread build) G ITSELF IS OVERWRITTEN (its first N * 64 doubles hold D-): it is dead once
+// the tridiagonalisation has loaded it.
 template <int N>
 __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int r, int nev, double* sig, double* lds, int* iwork /*LDS 64 ints*/,
                                      double* dwork /*LDS 128*/, long long* prof) {
@@ -398,12 +459,14 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
     for (int j = tid; j < nev; j += TTN_WG) { const double l = lam[j]; sig[j] = (l > 0.0) ? sqrt(l) : 0.0; bad |= (j < r) && !(l > 0.0); }
     if (__syncthreads_or(bad)) return 1;
     EIG_MARK(4)
-    wg_twisted<N>(r, lds, iwork, (lds_f64*)dwork);
+    wg_twisted<N>(r, lds, iwork, (lds_f64*)dwork, const_cast<double*>(Gg));
     EIG_MARK(5)
     // Z into registers: waves 0..7; a row of 16 lanes owns TWO columns (8 per wave), lane rc of the row holds rows RPL*rc ..
     // RPL*rc + RPL-1 of both — the dot products v_k' z are reductions over the 16 lanes of a row (4 DPP adds each): no LDS
     // reduction and no barrier in the loop.  The reflectors are staged in LDS once (the D+ / D- arrays are dead after the load of Z).
-    lds_f64 *Dp = L, *Dm = L + 64 * 128;
+    lds_f64* Dp = L;
+    EigDm<N> Dm;
+    Dm.l = L + N * 64; Dm.g = (typename EigDm<N>::gdouble*)(unsigned long long)Gg;
     // lane groups as in the Jacobi (grp_sum): the 16 lanes {B + 4g + 16k} form group g; member index rc; the 16-lane sums of the
     // two dot products per reflector then run on the matrix pipe (2 x 2 v_mfma_f64_4x4x4 instead of 2 x 12 VALU instructions)
     const int rc = (lane & 3) | ((lane >> 4) << 2), col0 = 8 * (wave & 7) + 2 * ((lane >> 2) & 3);
@@ -416,18 +479,22 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
 #pragma unroll
         for (int t = 0; t < RPL; ++t) {
             const int row = RPL * rc + t;
-            const double v = (row < kb) ? Dp[row * 64 + col] : ((row == kb) ? 1.0 : Dm[row * 64 + col]);
+            const double v = (row < kb) ? Dp[row * 64 + col] : ((row == kb) ? 1.0 : Dm.ld(row * 64 + col));
             z[cc][t] = v * zn;
         }
     }
+    // the reflectors go through the LDS image in chunks of as many rows as it holds (all N - 2 at once in the 1024-thread build)
+    constexpr int VROWS = TTN_LDS_IMG / 128;
+    for (int khi = N - 2; khi > 0; khi -= VROWS) {
+    const int klo = (khi > VROWS) ? khi - VROWS : 0;
     __syncthreads();
-    for (int e_ = tid; e_ < (N - 2) * 128; e_ += TTN_WG) L[e_] = Vst[e_];
+    for (int e_ = tid; e_ < (khi - klo) * 128; e_ += TTN_WG) L[e_] = Vst[klo * 128 + e_];
     __syncthreads();
     if (wave < 8) {
         typedef double __attribute__((ext_vector_type(2))) d2;
         typedef __attribute__((address_space(3))) d2 lds_d2;
-        for (int k = N - 3; k >= 0; --k) {
-            const lds_d2* vp = (const lds_d2*)(L + k * 128 + RPL * rc);
+        for (int k = khi - 1; k >= klo; --k) {
+            const lds_d2* vp = (const lds_d2*)(L + (k - klo) * 128 + RPL * rc);
             double vk[RPL];
 #pragma unroll
             for (int t = 0; t < RPL / 2; ++t) { const d2 w2 = vp[t]; vk[2 * t] = w2.x; vk[2 * t + 1] = w2.y; }
@@ -439,6 +506,7 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
 #pragma unroll
             for (int t = 0; t < RPL; ++t) { z[0][t] = fma(-t0, vk[t], z[0][t]); z[1][t] = fma(-t1, vk[t], z[1][t]); }
         }
+    }
     }
     __syncthreads();                                              // everyone has consumed D+ / D-: the image may be written
     EIG_MARK(6)

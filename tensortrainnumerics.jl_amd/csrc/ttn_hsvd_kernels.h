@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(TTN_WG) k_ttv_decomp(HsvdArgs H) {
     const CompressArgs& P = H.C;
     const TTDev& T = P.tt;
     const int b = blockIdx.x, tid = threadIdx.x, d = T.d;
-    if (tid == 0) { P.status[b] = 0; P.sweep_stats[b] = 0; }
+    if (tid == 0) P.sweep_stats[b] = 0;
     BondCtx S;
     S.ldsX = lds;
     S.red = lds + GEMM_LDS_TOTAL;

@@ -203,8 +203,10 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_add(TTDev x, TTDev y, TTDev z
 // ---------------------------------------------------------------------------------------------
 // scalar *: copy every core, scale core `which` by a (src/tt_operations.jl:256-266); zero==1 -> all-zero train
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TTN_STREAM_TB) k_scale(TTDev x, TTDev y, double a, int which, int zero) {
+// which_b (device, per train) overrides `which` when the trains of the batch carry different gauge flags
+__global__ void __launch_bounds__(TTN_STREAM_TB) k_scale(TTDev x, TTDev y, double a, int which, int zero, const int* which_b) {
     const int k = blockIdx.y, b = blockIdx.z;
+    if (which_b) which = which_b[b];
     const long long* xr = x.rks + (long long)b * (x.d + 1);
     const long long total = (long long)x.dims[k] * xr[k] * xr[k + 1];
     const double* Xk = x.data + (long long)b * x.stride + x.off[k];
@@ -215,8 +217,9 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_scale(TTDev x, TTDev y, doubl
 }
 
 // per-train scalar: y_b = a[b] * x_b (a on the device); a[b] == 0 writes the zero train
-__global__ void __launch_bounds__(TTN_STREAM_TB) k_scale_batch(TTDev x, TTDev y, const double* a, int which) {
+__global__ void __launch_bounds__(TTN_STREAM_TB) k_scale_batch(TTDev x, TTDev y, const double* a, int which, const int* which_b) {
     const int k = blockIdx.y, b = blockIdx.z;
+    if (which_b) which = which_b[b];
     const long long* xr = x.rks + (long long)b * (x.d + 1);
     const long long total = (long long)x.dims[k] * xr[k] * xr[k + 1];
     const double* Xk = x.data + (long long)b * x.stride + x.off[k];

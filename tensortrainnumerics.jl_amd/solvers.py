@@ -53,12 +53,11 @@ def _compress(x: DeviceTT, xr, max_bond: int):
     need, fin = D.compress_rank_bound(x.dims, xr, max_bond)
     if any(n > c for n, c in zip(need, x.cap)):
         big = DeviceTT(x.dims, need, x.batch)
-        import ctypes as C
-        from . import _lib
         _lib.check(_lib.lib().ttn_tt_copy(big.h, x.h))
         x.free()
         x = big
     D.tt_compress_(x, max_bond)
+    D.compress_status(x)        # a non-converged SVD inside a chain must not be committed silently (the codes are sticky per handle)
     return x, fin
 
 

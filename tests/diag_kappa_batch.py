@@ -23,6 +23,8 @@ for b in range(B):
     s = s[s >= 0]
     k = min(len(s), r)
     ks.append(s[0] / max(s[k - 1], 1e-300))
+order = np.argsort(np.array(ks))
+print("worst seeds (seed:kappa):", " ".join(f"{30 + int(b)}:{ks[b]:.3g}" for b in order[-16:]))
 ks = np.sort(np.array(ks))
 print(f"step {step}: kappa of the kept block over {B} trains: min {ks[0]:.3g} median {ks[B // 2]:.3g} 90% {ks[int(0.9 * B)]:.3g} 99% {ks[int(0.99 * B)]:.3g} max {ks[-1]:.3g}")
 print("largest:", " ".join(f"{v:.3g}" for v in ks[-8:]))

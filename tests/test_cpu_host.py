@@ -24,15 +24,75 @@ def T():
     return ttn_amd
 
 
-def test_library_exports_every_declared_symbol(T):
+def _header_prototypes():
+    """(return type, name, [argument types]) of every function include/ttn.h declares, comments stripped."""
     hdr = open(os.path.join(ROOT, "include", "ttn.h")).read()
-    declared = set(re.findall(r"\b(ttn_[a-z0-9_]+)\s*\(", hdr))
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    out = []
+    for ret, name, args in re.findall(r"\b(int|const char\*)\s+(ttn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
+        types = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a == "void":
+                continue
+            t = re.sub(r"\bconst\b", "", a)
+            t = re.sub(r"\s*[A-Za-z_][A-Za-z0-9_]*$", "", t.strip())        # drop the parameter name
+            types.append(re.sub(r"\s+", "", t))
+        out.append((ret, name, types))
+    return out
+
+
+def _ctypes_of(ctype: str):
+    """ctypes types a C parameter type of ttn.h may be bound as (device pointers travel as c_void_p)."""
+    L = ctypes
+    table = {
+        "int": [L.c_int], "int64_t": [L.c_int64], "double": [L.c_double],
+        "int*": [L.POINTER(L.c_int), L.c_void_p], "int64_t*": [L.POINTER(L.c_int64), L.c_void_p],
+        "double*": [L.POINTER(L.c_double), L.c_void_p], "float*": [L.POINTER(L.c_float)],
+        "double**": [L.POINTER(L.POINTER(L.c_double))],
+        "ttn_tt_t": [L.c_void_p], "ttn_tto_t": [L.c_void_p], "ttn_tt_t*": [L.POINTER(L.c_void_p)], "ttn_tto_t*": [L.POINTER(L.c_void_p)],
+    }
+    return table[ctype]
+
+
+def test_library_exports_every_declared_symbol(T):
+    protos = _header_prototypes()
+    declared = {name for _, name, _ in protos}
     assert len(declared) >= 35
     lib = ctypes.CDLL(T._lib.LIB_PATH)
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f"libttn_hip.so does not export: {missing}"
     assert declared == set(T._lib.SIGNATURES), "ctypes signature table out of sync with ttn.h"
     assert b"gfx950" in T._lib.lib().ttn_version()
+
+
+def test_ctypes_signatures_match_header_argument_types(T):
+    """Not only the names: return type, arity and every argument type of the ctypes table against the prototypes of ttn.h."""
+    for ret, name, types in _header_prototypes():
+        res, args = T._lib.SIGNATURES[name]
+        assert res is (ctypes.c_char_p if ret == "const char*" else ctypes.c_int), name
+        assert len(args) == len(types), f"{name}: header has {len(types)} arguments, ctypes table {len(args)}"
+        for i, (ct, at) in enumerate(zip(types, args)):
+            ok = any(at is c or (hasattr(at, "_type_") and hasattr(c, "_type_") and at._type_ is c._type_) for c in _ctypes_of(ct))
+            assert ok, f"{name}: argument {i} is `{ct}` in ttn.h but {at} in _lib.SIGNATURES"
+    hdr = open(os.path.join(ROOT, "include", "ttn.h")).read()
+    for code, val in re.findall(r"#define\s+(TTN_(?:OK|ERR_[A-Z_]+))\s+(-?\d+)", hdr):
+        assert getattr(T._lib, code) == int(val), f"{code} differs between ttn.h and _lib.py"
+
+
+def test_header_is_usable_from_plain_c(T, tmp_path):
+    """include/ttn.h compiled as C99 and linked against the .so the way a `ccall` binds it: the program calls two entry
+    points that need no GPU (tests/c_abi_probe.c)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "c_abi_probe")
+    libdir = os.path.dirname(T._lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi_probe.c"), "-o", exe, "-L", libdir, "-l:libttn_hip.so",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "gfx950" in out and "rks = 1 2 1" in out and "rks = 1 4 1" in out and "not-init rc = -7" in out, out
 
 
 def test_library_contains_gfx950_code_object(T):
