@@ -112,7 +112,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", LIB_PATH, os.path.join(CSRC, "ttn_api.hip")]
+           "-o", LIB_PATH, os.path.join(CSRC, "ttn_api.hip"), os.path.join(CSRC, "ttn_wg512.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -17,10 +17,20 @@
 #include <string>
 #include <vector>
 
+// the 512-thread build of k_compress and its building blocks (ttn_wg512.hip: two workgroups per CU)
+extern "C" {
+int ttn_wg512_init(void);
+size_t ttn_wg512_compress_args_bytes(void);
+int ttn_wg512_launch_compress(const void* args, size_t nbytes, int grid, hipStream_t stream);
+int ttn_wg512_selftest_eig(const double* G, double* Vst, int n, int r, int nev, double* sig, double* Xout, long long* clk, hipStream_t stream);
+int ttn_wg512_selftest_gemm(int m, int n, int k, double* A, double* B, double* C, double alpha, double beta, int ta, int tb, hipStream_t stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // global state
 // ------------------------------------------------------------------------------------------------
 namespace {
+int* g_next_train = nullptr;  // train counter of the persistent k_compress grid
 std::recursive_mutex g_mu;
 bool g_init = false;
 int g_device = -1;
@@ -162,6 +172,10 @@ int ttn_init(int device) {
                                (int)(sizeof(double) * GEMM_LDS_TOTAL)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(COMPRESS_LDS_BYTES)));
+    { const int rc512 = ttn_wg512_init(); if (rc512) return hipfail((hipError_t)rc512, "ttn_wg512_init"); }
+    static_assert(sizeof(CompressArgs) > 0, "");
+    if (ttn_wg512_compress_args_bytes() != sizeof(CompressArgs)) return fail(TTN_ERR_ARG, "ttn_init: the two kernel builds disagree on CompressArgs");
+    HIPCHK(hipMalloc((void**)&g_next_train, sizeof(int)));
     g_device = device;
     g_init = true;
     return TTN_OK;
@@ -173,6 +187,8 @@ int ttn_finalize(void) {
     hipStreamSynchronize(g_stream);
     if (g_scratch) hipFree(g_scratch);
     if (g_dout) hipFree(g_dout);
+    if (g_next_train) hipFree(g_next_train);
+    g_next_train = nullptr;
     g_scratch = nullptr; g_scratch_bytes = 0; g_dout = nullptr; g_dout_cap = 0;
     hipEventDestroy(g_ev0); hipEventDestroy(g_ev1);
     for (auto e : g_slots) if (e) hipEventDestroy(e);
@@ -661,6 +677,17 @@ int ttn_compress_rank_bound(int64_t d, const int64_t* dims, const int64_t* rks, 
 // Everything that can refuse a compress launch — capacity of the handle for the ranks the sweep can reach from `bound`, the size
 // limits of the merged matrices, the scratch allocation — checked WITHOUT touching the handle (ttn_apply_compress runs this on the
 // product's ranks before it overwrites y's).
+// Which build runs a compress launch, and on how many workgroup slots.  More trains than CUs: the 512-thread build on a PERSISTENT
+// grid of two workgroups per CU that pull trains from a counter (scratch per slot); otherwise one 1024-thread workgroup per train
+// (lowest latency for a single train).  TTN_WG512=1 / 0 forces / forbids the 512-thread build (diagnostics, parity tests).
+#define TTN_NUM_CUS 256
+static bool compress_use_wg512(int batch) {
+    const char* e = getenv("TTN_WG512");
+    if (e) return atoi(e) != 0;
+    return batch > TTN_NUM_CUS;
+}
+static int compress_slots(int batch) { return compress_use_wg512(batch) ? std::min(batch, 2 * TTN_NUM_CUS) : batch; }
+
 static int compress_precheck(ttn_tt_t psi, const std::vector<int64_t>& bound, int64_t k_single, int64_t max_bond, int64_t sweeps,
                              int64_t k_first, int64_t k_last, std::vector<int64_t>& fin, long long& pmax, long long& qmax, long long& per_train) {
     const int d = psi->d;
@@ -671,7 +698,7 @@ static int compress_precheck(ttn_tt_t psi, const std::vector<int64_t>& bound, in
         if (need[m] > psi->cap[m]) return fail(TTN_ERR_CAPACITY, "ttn_compress: a bond rank can grow beyond the handle's capacity (see ttn_compress_rank_bound)");
     if (pmax > 4096 || qmax > 16384) return fail(TTN_ERR_UNSUPPORTED, "ttn_compress: merged matrix larger than 4096 x 16384");
     per_train = 2 * pmax * qmax + QR_NB * qmax + pmax * QR_NB + 2 * pmax * pmax + 4 * pmax + 64 + 6 * 128 * 128;
-    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * psi->batch);
+    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * compress_slots(psi->batch));
     if (rc) return rc;
     return ensure_batch_bufs(psi->batch);
 }
@@ -722,8 +749,16 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     { const char* e = getenv("TTN_JTOL"); P.jtol_mult = e ? atof(e) : 1.0; }
     { const char* e = getenv("TTN_JNEG"); P.jneg_mult = e ? atof(e) : 1.0; }
     { const char* e = getenv("TTN_FAST"); P.fast = e ? atoi(e) : 1; }
-    hipLaunchKernelGGL(k_compress, dim3(psi->batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, P);
-    HIPCHK(hipGetLastError());
+    if (compress_use_wg512(psi->batch)) {
+        HIPCHK(hipMemsetAsync(g_next_train, 0, sizeof(int), g_stream));
+        P.next_train = g_next_train;
+        const int rc512 = ttn_wg512_launch_compress(&P, sizeof(P), compress_slots(psi->batch), g_stream);
+        if (rc512) return hipfail((hipError_t)rc512, "k_compress (512-thread build)");
+    } else {
+        P.next_train = nullptr;
+        hipLaunchKernelGGL(k_compress, dim3(psi->batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, P);
+        HIPCHK(hipGetLastError());
+    }
     psi->bound = fin;
     return TTN_OK;
 }
@@ -1353,9 +1388,14 @@ int ttn_selftest_gemm(int64_t m, int64_t n, int64_t k, const double* A, const do
     HIPCHK(hipMemcpyAsync(dA, A, sizeof(double) * m * k, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemcpyAsync(dB, B, sizeof(double) * k * n, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemcpyAsync(dC, C, sizeof(double) * m * n, hipMemcpyHostToDevice, g_stream));
+    if (getenv("TTN_WG512_SELFTEST") && atoi(getenv("TTN_WG512_SELFTEST"))) {       // the same test against the 512-thread build
+        const int rc512 = ttn_wg512_selftest_gemm((int)m, (int)n, (int)k, dA, dB, dC, alpha, beta, ta, tb, g_stream);
+        if (rc512) return hipfail((hipError_t)rc512, "k_selftest_gemm (512-thread build)");
+    } else {
     hipLaunchKernelGGL(k_selftest_gemm, dim3(1), dim3(TTN_WG), sizeof(double) * GEMM_LDS_TOTAL, g_stream, (int)m, (int)n, (int)k,
                        dA, dB, dC, alpha, beta, ta, tb);
     HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMemcpyAsync(C, dC, sizeof(double) * m * n, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     hipFree(dA); hipFree(dB); hipFree(dC);
@@ -1377,8 +1417,13 @@ int ttn_selftest_eig128(const double* G, int64_t n, int64_t r, int64_t nev, doub
     HIPCHK(hipMalloc((void**)&dC, sizeof(long long) * 16));
     HIPCHK(hipMemcpyAsync(dG, G, sizeof(double) * n * n, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(dX, 0, sizeof(double) * 128 * 64, g_stream));
+    if (getenv("TTN_WG512_SELFTEST") && atoi(getenv("TTN_WG512_SELFTEST"))) {
+        const int rc512 = ttn_wg512_selftest_eig(dG, dV, (int)n, (int)r, (int)nev, dS, dX, dC, g_stream);
+        if (rc512) return hipfail((hipError_t)rc512, "k_selftest_eig128 (512-thread build)");
+    } else {
     hipLaunchKernelGGL(k_selftest_eig128, dim3(1), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, dG, dV, (int)n, (int)r, (int)nev, dS, dX, dC);
     HIPCHK(hipGetLastError());
+    }
     long long hc[16] = {0};
     HIPCHK(hipMemcpyAsync(sig, dS, sizeof(double) * nev, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipMemcpyAsync(X, dX, sizeof(double) * 128 * r, hipMemcpyDeviceToHost, g_stream));

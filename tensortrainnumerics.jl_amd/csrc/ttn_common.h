@@ -7,6 +7,14 @@
 #define TTN_WG 1024            // threads of the dense (one-workgroup-per-train) kernels (512 is supported for experiments)
 #endif
 #define TTN_NWAVES (TTN_WG / 64)
+// Register budget of the dense kernels: 128 VGPRs per lane in both builds.  1024 threads = 4 waves per SIMD already imply it; the
+// 512-thread build asks for 4 waves per SIMD explicitly (second launch-bounds argument = minimum waves per execution unit), i.e.
+// two resident workgroups per CU — without it the compiler would take up to 256 registers and one workgroup would own the CU.
+#if TTN_WG == 512
+#define TTN_KERNEL_BOUNDS __launch_bounds__(512, 4)
+#else
+#define TTN_KERNEL_BOUNDS __launch_bounds__(TTN_WG)
+#endif
 #define TTN_MAX_D 64           // max chain length handled by the on-stack tables of the host API
 #define TTN_SV_NONE (-1)
 

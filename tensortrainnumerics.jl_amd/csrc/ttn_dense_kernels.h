@@ -925,8 +925,19 @@ __device__ __noinline__ void wg_lq_blocked(int p, int q, double* M2, int ld, dou
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) atomicAdd(&Ss[(lk + 4 * reg) * QR_NB + li], acc[reg]);
             __syncthreads();
-        } else
-        wg_gemm(jb, jb, len, Vv, tview(Vv), mkview(Ss, plain(QR_NB), plain(1)), 1.0, 0.0, lds_gemm);
+        } else {
+            // panel too long for the LDS form (V is in global memory): 256 dot products, one wave each.  NOT a wg_gemm call: Ss is
+            // LDS and the GEMM stores through global-address-space pointers (that call faulted on the first matrix long enough to
+            // get here: q > 412 in the 512-thread build, q > 796 in the 1024-thread one)
+            for (int e = wave; e < jb * jb; e += nwaves) {
+                const int i = e / jb, j = e - i * jb;
+                double a = 0.0;
+                for (int c = lane; c < len; c += 64) a = fma(Vb[(long long)i * len + c], Vb[(long long)j * len + c], a);
+                a = wave_sum(a);
+                if (lane == 0) Ss[i * QR_NB + j] = a;
+            }
+            __syncthreads();
+        }
         if (tid < QR_NB) {                                // lane i builds row i of T: it only needs its own row
             const int i = tid;
             for (int j = 0; j < QR_NB; ++j) Ts[i * QR_NB + j] = 0.0;
@@ -1905,7 +1916,6 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         const View Gav = mkview(S.Ga, plain(1), plain(128));
         const View Gbv = mkview(S.Gb, plain(1), plain(128));
         const View Ccv = mkview(S.Cc, plain(1), plain(128));
-        const View Xlv = mkview(S.ldsX, plain(1), plain(128));
         bool diagA = false;
         if (ok) {
             wg_gemm(rm, rm, p, tview(Ap), Ap, Gav, 1.0 / (sA * sA), 0.0, lds);          // A'^T A'
@@ -2339,7 +2349,7 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
     wg_bond_step_io<0>(P, b, io, k, step, lds, virt);
 }
 
-__global__ void __launch_bounds__(TTN_WG) k_compress(CompressArgs P) {
+__global__ void TTN_KERNEL_BOUNDS k_compress(CompressArgs P) {
     extern __shared__ double lds[];
     const int d = P.tt.d;
     // ONE call site of the (force-inlined) bond step: as an out-of-line function it received its arguments in VGPRs, so
@@ -2400,7 +2410,7 @@ struct ChainArgs {
     TTDev x, y, z;               // kind 1
 };
 
-__global__ void __launch_bounds__(TTN_WG) k_swap_chain(ChainArgs Q) {
+__global__ void TTN_KERNEL_BOUNDS k_swap_chain(ChainArgs Q) {
     extern __shared__ double lds[];
     const CompressArgs& P = Q.C;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -2508,7 +2518,7 @@ struct DotArgs {
     double* out;                // [batch] device
 };
 
-__global__ void __launch_bounds__(TTN_WG) k_dot(DotArgs P) {
+__global__ void TTN_KERNEL_BOUNDS k_dot(DotArgs P) {
     extern __shared__ double lds[];
     const int t = blockIdx.x;
     const TTDev& A = P.a; const TTDev& B = P.b;
@@ -2547,7 +2557,7 @@ __global__ void __launch_bounds__(TTN_WG) k_dot(DotArgs P) {
 // kernel unit-test hook for wg_gemm (tests/test_gpu_kernels.py): one workgroup, plain row-major operands
 // (optionally viewed transposed so both LDS staging maps are exercised)
 // -------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TTN_WG) k_selftest_gemm(int m, int n, int k, double* A, double* B, double* C, double alpha,
+__global__ void TTN_KERNEL_BOUNDS k_selftest_gemm(int m, int n, int k, double* A, double* B, double* C, double alpha,
                                                          double beta, int ta, int tb) {
     extern __shared__ double lds[];
     const View Av = ta ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));     // ta: A stored k x m
@@ -2555,7 +2565,7 @@ __global__ void __launch_bounds__(TTN_WG) k_selftest_gemm(int m, int n, int k, d
     wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), alpha, beta, lds);
 }
 
-__global__ void __launch_bounds__(TTN_WG) k_bench_gemm(int m, int n, int k, double* A, double* B, double* C, int ta, int tb, int reps,
+__global__ void TTN_KERNEL_BOUNDS k_bench_gemm(int m, int n, int k, double* A, double* B, double* C, int ta, int tb, int reps,
                                                       long long* cycles) {
     extern __shared__ double lds[];
     const View Av = ta ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));
@@ -2569,7 +2579,7 @@ __global__ void __launch_bounds__(TTN_WG) k_bench_gemm(int m, int n, int k, doub
 }
 
 // LDS building-block micro-benchmark (ttn_bench_lds): G = I*n + smooth symmetric perturbation, then Cholesky or Jacobi.
-__global__ void __launch_bounds__(TTN_WG) k_bench_lds(int what, int n, int reps, long long* out) {
+__global__ void TTN_KERNEL_BOUNDS k_bench_lds(int what, int n, int reps, long long* out) {
     extern __shared__ double lds[];
     double* red = lds + GEMM_LDS_TOTAL;
     double* scal = red + 32;

@@ -532,7 +532,7 @@ __device__ int wg_eig64(const double* Gg, int ldg, double* Vst, int r, int nev, 
     return wg_eig_n<64>(Gg, ldg, Vst, r, nev, sig, lds, iwork, dwork, nullptr);
 }
 
-__global__ void __launch_bounds__(TTN_WG) k_selftest_eig128(const double* G, double* Vst, int n, int r, int nev, double* sig, double* Xout, long long* clk) {
+__global__ void TTN_KERNEL_BOUNDS k_selftest_eig128(const double* G, double* Vst, int n, int r, int nev, double* sig, double* Xout, long long* clk) {
     extern __shared__ double lds[];
     int* iwork = reinterpret_cast<int*>(lds + GEMM_LDS_TOTAL + 32);
     double* dwork = lds + GEMM_LDS_TOTAL + 32 + 64;
