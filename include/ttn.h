@@ -150,12 +150,24 @@ int ttn_mals_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double t
  * (windows 1..d-2 forward with right_core_move!, d-1..2 backward with left_core_move!, dmrg.jl:187-232) walked through the
  * reference's stage schedule — sweep s ends stage j when s == sweep_schedule[j], the sweep that would end the last stage is
  * the closing solve at window 1 — with the ranks cut by cut_off_index (dmrg.jl:179-185) clamped to the stage's rmax.
- * Every local system is assembled densely and solved by LU (the reference's `K_full` + `K \ Pb` branch, dmrg.jl:57-62,
- * :173-175; its default KrylovKit branch solves the same system to linsolv_tol only).  sweep_schedule must be positive and
+ * Local systems up to 2048 unknowns are assembled densely and solved by LU (the reference's `K_full` + `K \ Pb` branch,
+ * dmrg.jl:57-62, :173-175), larger ones matrix-free by conjugate gradients (see ttn_dmrg_linsolve_it).  sweep_schedule must be positive and
  * strictly increasing (anything else does not terminate in the reference); at most 32 full sweeps per call.  Capacity and
  * status as for ttn_mals_linsolve.  N = 1 is ttn_als_linsolve's territory and not offered here. */
 int ttn_dmrg_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t n_stages, const int64_t* sweep_schedule,
                       const int64_t* rmax_schedule);
+
+/* The same with the reference's local-solver keywords (dmrg.jl:392-396, :92-97): every local system with `it_solver != 0` or with
+ * more than `itslv_thresh` unknowns is solved MATRIX-FREE by conjugate gradients on the symmetrised local operator (dmrg.jl:99-171:
+ * the three-tensor sandwich G (x) Amid (x) H as fp64 MFMA GEMMs; KrylovKit's `linsolve(...; issymmetric, isposdef, tol, maxiter)`):
+ * start vector = the current two-site block, stop at ||residual||_2 < linsolv_tol (absolute) or after linsolv_maxiter iterations.
+ * The reference's defaults are it_solver = 1, linsolv_maxiter = 200, linsolv_tol = max(sqrt(tol), 1e-8), itslv_thresh = 256.
+ * Dense systems are limited to 2048 unknowns; anything larger is solved matrix-free whatever the keywords say, so two-site
+ * systems up to n_i cap_i = n_{i+1} cap_{i+2} = 256 (ranks 128 for n = 2: 65 536 unknowns, BASELINE config C5) are in reach.
+ * ttn_dmrg_linsolve itself = it_solver 0, itslv_thresh 2048.  ttn_dmrg_cg_iterations: CG iterations per train of the last call. */
+int ttn_dmrg_linsolve_it(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t n_stages, const int64_t* sweep_schedule,
+                         const int64_t* rmax_schedule, int it_solver, int64_t linsolv_maxiter, double linsolv_tol, int64_t itslv_thresh);
+int ttn_dmrg_cg_iterations(int64_t batch, int64_t* iters);
 
 /* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);

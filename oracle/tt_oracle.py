@@ -947,11 +947,39 @@ def dmrg_sweep_plan(sweep_schedule: Sequence[int], rmax_schedule: Sequence[int])
         plan.append(int(rmax_schedule[j]))
 
 
+def cg_solve(apply_K, rhs: np.ndarray, x0: np.ndarray, tol: float, maxiter: int):
+    """Conjugate gradients as KrylovKit's `linsolve(f, b, x0; issymmetric = true, isposdef = true, tol, maxiter)` runs them (the
+    call at src/solvers/dmrg.jl:170; KrylovKit is a third-party dependency, compat 0.6.1 / 0.9 / 0.10, not in the reference tree —
+    this is its published CG recurrence): r = b - K x0; stop when ||r||_2 < tol (ABSOLUTE) or after maxiter iterations, returning
+    the current iterate either way.  Returns (x, iterations)."""
+    x = x0.copy()
+    r = rhs - apply_K(x)
+    rho = float(r @ r)
+    p = r.copy()
+    it = 0
+    while not (math.sqrt(rho) < tol) and it < maxiter:
+        q = apply_K(p)
+        alpha = rho / float(p @ q)
+        x += alpha * p
+        r -= alpha * q
+        rho_new = float(r @ r)
+        beta = rho_new / rho
+        rho = rho_new
+        it += 1
+        if math.sqrt(rho) < tol:
+            break
+        p = r + beta * p
+    return x, it
+
+
 def dmrg_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1.0e-12, sweep_schedule: Sequence[int] = (2,),
-                  rmax_schedule: Sequence[int] | None = None) -> TTvector:
-    """dmrg_linsolve(A, b, tt_start; N = 2, tol, sweep_schedule, rmax_schedule) (src/solvers/dmrg.jl:388-472) with every local
-    system solved densely (`K_full` + `K \\ Pb`, dmrg.jl:57-62, :173-175 — the branch the reference takes for
-    it_solver = false and small systems; its default KrylovKit branch solves the same system to linsolv_tol only).
+                  rmax_schedule: Sequence[int] | None = None, it_solver: bool = False, linsolv_maxiter: int = 200,
+                  linsolv_tol: float | None = None, itslv_thresh: int = 10 ** 9, stats: dict | None = None) -> TTvector:
+    """dmrg_linsolve(A, b, tt_start; N = 2, tol, sweep_schedule, rmax_schedule, it_solver, linsolv_maxiter, linsolv_tol,
+    itslv_thresh) (src/solvers/dmrg.jl:388-472).  Local systems (Ksolve!, :92-177): dense (`K_full` + `K \\ Pb`, :57-62, :173-175)
+    unless `it_solver` or the system has more than `itslv_thresh` unknowns; then conjugate gradients (cg_solve) on the symmetrised
+    matrix-free operator 1/2 (K + K^T) of :99-168 started from V0 = the current two-site block (:311-316, :329-334).  Defaults here:
+    dense everywhere (the reference's own defaults are it_solver = true, itslv_thresh = 256, linsolv_tol = max(sqrt(tol), 1e-8)).
     Environments G (R, r, r) / H (R, r, r) (dmrg.jl:27-35), merged operator / right-hand-side cores Amid / b_mid (:38-47, :89-96),
     core moves right_core_move! / left_core_move! (:187-232)."""
     d = b.N
@@ -988,12 +1016,43 @@ def dmrg_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1
     for i in range(d - 2, 0, -1):
         upd_H(i)
 
+    if linsolv_tol is None:
+        linsolv_tol = max(math.sqrt(tol), 1.0e-8)                      # dmrg.jl:394
+
+    # start vector of the iterative local solve (V0_view): b_mid(tt_opt, 1, 2) at first (dmrg.jl:275), then what update_right
+    # (:311-316) / update_left (:329-334) build from the moved factor V_move and the neighbouring core.  update_left reshapes
+    # [alpha, J, i_k, gamma] with J (site i) running FASTER than i_k (site i-1): the two physical indices end up exchanged with
+    # respect to the (site i-1 fast) convention of K_dims — restated as it is (it only is a start vector).
+    v0 = {"V": None}
+
     def ksolve(i):
         Gi, Hi = G[i], H[i]
         kd = (Gi.shape[1], Amid[i].shape[1], Hi.shape[1])
         N = kd[0] * kd[1] * kd[2]
-        K = np.reshape(np.einsum("yad,zcf,ybez->abcdef", Gi, Hi, Amid[i], optimize=True), (N, N), order="F")
         Pb = np.einsum("ap,piq,cq->aic", Gb[i], bmid[i], Hb[i], optimize=True)
+        if it_solver or N > itslv_thresh:
+            Am = Amid[i]
+
+            def apply_K(v):                                             # 1/2 (K + K^T) v, the intended contraction of dmrg.jl:165:
+                V = np.reshape(v, kd, order="F")                        # Hrshp[a,b,c] = G[y,a,d] H[z,c,f] Amid[y,b,e,z] V[d,e,f] + transposes
+                W = np.tensordot(Gi, V, axes=([2], [0]))                # [y, a, e, f]
+                U = np.tensordot(Am, W, axes=([0, 2], [0, 2]))          # [b, z, a, f]
+                t1 = np.tensordot(U, Hi, axes=([1, 3], [0, 2]))         # [b, a, c]
+                W = np.tensordot(Gi, V, axes=([1], [0]))                # G[y,d,a] V[d,e,f] -> [y, a, e, f]
+                U = np.tensordot(Am, W, axes=([0, 1], [0, 2]))          # Amid[y,e,b,z] -> [b, z, a, f]
+                t2 = np.tensordot(U, Hi, axes=([1, 3], [0, 1]))         # H[z,f,c] -> [b, a, c]
+                return 0.5 * np.reshape(np.transpose(t1 + t2, (1, 0, 2)), N, order="F")
+
+            V0 = v0["V"]
+            if V0 is None:                                              # b_mid(tt_opt, 1, 2)
+                V0 = np.reshape(np.einsum("ajg,kgb->ajkb", np.transpose(x.ttv_vec[i], (1, 0, 2)), x.ttv_vec[i + 1]), kd, order="F")
+            assert V0.shape == kd, (V0.shape, kd)
+            v, iters = cg_solve(apply_K, np.reshape(Pb, N, order="F"), np.reshape(V0, N, order="F").copy(), linsolv_tol, linsolv_maxiter)
+            if stats is not None:
+                stats["cg_iterations"] = stats.get("cg_iterations", 0) + iters
+                stats["cg_solves"] = stats.get("cg_solves", 0) + 1
+            return np.reshape(v, kd, order="F")
+        K = np.reshape(np.einsum("yad,zcf,ybez->abcdef", Gi, Hi, Amid[i], optimize=True), (N, N), order="F")
         Ku = np.triu(K) + np.triu(K, 1).T                              # Hermitian(K): the upper triangle
         V = sla.solve(Ku, np.reshape(Pb, N, order="F"), assume_a="sym")
         return np.reshape(V, kd, order="F")
@@ -1020,10 +1079,14 @@ def dmrg_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1
 
     for rmax in plan:
         for i in range(d - 2):                                        # first half sweep (:446-456)
-            right_move(ksolve(i), i, rmax)
+            Vm = right_move(ksolve(i), i, rmax)                        # (r_{i+1}, n_{i+1}, r_{i+2})
+            t = np.einsum("aJb,kbg->aJkg", Vm, x.ttv_vec[i + 2])       # update_right: [alpha, J, i_k, gamma]
+            v0["V"] = np.reshape(t, (t.shape[0], -1, t.shape[3]), order="F")
             upd_G(i)
         for i in range(d - 2, 0, -1):                                 # second half sweep (:459-470)
-            left_move(ksolve(i), i, rmax)
+            Vm = left_move(ksolve(i), i, rmax)                         # (r_i, n_i, r_{i+1})
+            t = np.einsum("bJg,kab->aJkg", Vm, x.ttv_vec[i - 1])       # update_left: [alpha, J, i_k, gamma], J = site i FAST
+            v0["V"] = np.reshape(t, (t.shape[0], -1, t.shape[3]), order="F")
             upd_H(i)
     Vm = left_move(ksolve(0), 0, rmax_final)                          # closing step (:426-441)
     x.ttv_vec[0] = np.transpose(np.reshape(Vm, (1, dims[0], -1), order="F"), (1, 0, 2)).copy()

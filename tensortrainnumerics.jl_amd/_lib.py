@@ -72,6 +72,8 @@ SIGNATURES = {
     "ttn_als_linsolve": (C.c_int, [handle, handle, handle, handle, i64]),
     "ttn_mals_linsolve": (C.c_int, [handle, handle, handle, handle, C.c_double, i64]),
     "ttn_dmrg_linsolve": (C.c_int, [handle, handle, handle, handle, C.c_double, i64, p_i64, p_i64]),
+    "ttn_dmrg_linsolve_it": (C.c_int, [handle, handle, handle, handle, C.c_double, i64, p_i64, p_i64, C.c_int, i64, C.c_double, i64]),
+    "ttn_dmrg_cg_iterations": (C.c_int, [i64, p_i64]),
     "ttn_selftest_eig128": (C.c_int, [C.c_void_p, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ttn_add": (C.c_int, [handle, handle, handle]),
     "ttn_scale": (C.c_int, [C.c_double, handle, handle]),

@@ -184,6 +184,68 @@ __device__ __noinline__ int wg_lu_solve(int N, double* K_, double* rhs_, int* pi
     return 0;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Matrix-free local solve of the two-site solvers (src/solvers/dmrg.jl:92-171, the branch `it_solver || N > itslv_thresh`):
+// conjugate gradients on the SYMMETRISED local operator
+//     K_s v = 1/2 (K + K^T) v,   K[(ab,cd),(ef,gh)] = sum_z G_z[ab,ef] H_z[cd,gh]
+// (the reference symmetrises the same way, dmrg.jl:135-166; its operator is the three-tensor sandwich G (x) Amid (x) H, which is
+// this Kronecker sum with the window's first / second operator core folded into G / H).  With the unknown viewed as the na x nb
+// matrix V, K v = sum_z G_z V H_z^T and K^T v = sum_z G_z^T V H_z: per application 2 R_z products na x nb x na into the slab
+// W = [W_1 ... W_R] and two products na x nb x (R_z nb) against the stacked H — all on the fp64 MFMA GEMM (wg_gemm), no K anywhere:
+// the 65 536-unknown systems of rank-128 trains (a 34 GB matrix) need 2 MB of G, 2 MB of H and a 2 MB slab.
+// The iteration is KrylovKit's CG (the reference's `linsolve(...; issymmetric, isposdef)`): start from x0, stop when ||r||_2 < tol
+// (ABSOLUTE, as `tol` is passed there) or after maxiter iterations, in which case the current iterate is returned like there.
+// G: (na, na, Rz) column-major; H: (Rz, nb, nb) with z fastest; x (in: x0, out: solution), rhs, and the work vectors r, p, q: N = na*nb
+// doubles each; W: na*nb*Rz.  Returns the number of iterations.
+// -------------------------------------------------------------------------------------------------
+__device__ __noinline__ int wg_cg_two_site(int na, int nb, int Rz, double* G, double* H, double* x, const double* rhs, double* r, double* p, double* q,
+                                           double* W, double tol, int maxiter, double* red, double* lds) {
+    na = uni32(na); nb = uni32(nb); Rz = uni32(Rz); maxiter = uni32(maxiter);
+    G = unip(G); H = unip(H); x = unip(x); rhs = unip(rhs); r = unip(r); p = unip(p); q = unip(q); W = unip(W); red = unip(red); lds = unip(lds);
+    const int N = na * nb;
+    const int tid = threadIdx.x;
+    // out = K_s v
+    auto apply = [&](double* v, double* out) {
+        const View Vv = mkview(v, plain(1), plain(na));
+        const View Ov = mkview(out, plain(1), plain(na));
+        const View Wcat = mkview(W, plain(1), plain(na));                                        // na x (Rz nb): column gh + nb z
+        for (int z = 0; z < Rz; ++z)                                                              // W_z = G_z V
+            wg_gemm(na, nb, na, mkview(G + (long long)na * na * z, plain(1), plain(na)), Vv, mkview(W + (long long)N * z, plain(1), plain(na)), 1.0, 0.0, lds);
+        // out = 1/2 sum_z W_z H_z^T:  B[(gh, z), cd] = H[z, cd, gh]
+        wg_gemm(na, nb, Rz * nb, Wcat, mkview(H, Idx{nb, (long long)Rz * nb, 1}, plain(Rz)), Ov, 0.5, 0.0, lds);
+        for (int z = 0; z < Rz; ++z)                                                              // W_z = G_z^T V
+            wg_gemm(na, nb, na, tview(mkview(G + (long long)na * na * z, plain(1), plain(na))), Vv, mkview(W + (long long)N * z, plain(1), plain(na)), 1.0, 0.0, lds);
+        // out += 1/2 sum_z W_z H_z:    B[(gh, z), cd] = H[z, gh, cd]
+        wg_gemm(na, nb, Rz * nb, Wcat, mkview(H, Idx{nb, (long long)Rz, 1}, plain((long long)Rz * nb)), Ov, 0.5, 1.0, lds);
+    };
+    auto dot = [&](const double* u, const double* v) {
+        double a = 0.0;
+        for (int e = tid; e < N; e += TTN_WG) a = fma(u[e], v[e], a);
+        return unif64(wg_sum(a, red));
+    };
+    apply(x, q);
+    for (int e = tid; e < N; e += TTN_WG) { const double re = rhs[e] - q[e]; r[e] = re; p[e] = re; }
+    __syncthreads();
+    double rho = dot(r, r);
+    int it = 0;
+    while (!(sqrt(rho) < tol) && it < maxiter) {
+        apply(p, q);
+        const double pq = dot(p, q);
+        const double alpha = rho / pq;
+        for (int e = tid; e < N; e += TTN_WG) { x[e] = fma(alpha, p[e], x[e]); r[e] = fma(-alpha, q[e], r[e]); }
+        __syncthreads();
+        const double rho_new = dot(r, r);
+        const double beta = rho_new / rho;
+        rho = rho_new;
+        ++it;
+        if (sqrt(rho) < tol) break;
+        for (int e = tid; e < N; e += TTN_WG) p[e] = fma(beta, p[e], r[e]);
+        __syncthreads();
+    }
+    __syncthreads();
+    return it;
+}
+
 // Shared by als_linsolve and mals_linsolve: G_{i+1}, Gb_{i+1} from site i (als.jl:47-55).  `xr` = the ranks of x to use.
 struct AlsEnv {
     TTODev A; TTDev b, x;
@@ -458,6 +520,13 @@ struct MalsArgs {
     //         rank rule cut_off_index (dmrg.jl:179-185).
     int mode, nsweeps, rmax_final;
     int rmax_sweep[TTN_DMRG_MAX_SWEEPS];
+    // local solver (dmrg.jl:92-97): conjugate gradients (wg_cg_two_site) if cg_all or the system has more than cg_above unknowns,
+    // dense LU otherwise.  offCg: per-train work area (4 vectors of Nmax doubles, then the slab Rzmax * Nmax); cg_iters: [batch]
+    // total CG iterations (diagnostics) or null.
+    int cg_all, cg_above, cg_maxiter;
+    double cg_tol;
+    long long offCg, cg_nmax;
+    int* cg_iters;
 };
 
 __global__ void __launch_bounds__(TTN_WG) k_mals_linsolve(MalsArgs Q) {
@@ -549,13 +618,44 @@ __global__ void __launch_bounds__(TTN_WG) k_mals_linsolve(MalsArgs Q) {
         __syncthreads();
     };
     // two-site solve at sites i, i+1: V (n1, r_i, n2, r_{i+2}) column-major in Pb
-    auto ksolve = [&](int i, int& a_out, int& b_out) -> bool {
+    auto ksolve = [&](int i, int& a_out, int& b_out, bool v0_swapped) -> bool {
         const int n1 = uni32(P.x.dims[i]), n2 = uni32(P.x.dims[i + 1]);
         const int rl = uni32((int)xr[i]), rr = uni32((int)xr[i + 2]);
         const int Rz = uni32((int)P.A.rks[i + 1]), bz = uni32((int)br_[i + 1]);
         const double *Gi = GP(i), *Gbi = GBP(i), *Hi = HP(i), *Hbi = HBP(i);
         const int na = n1 * rl, nb = n2 * rr, N = na * nb;
         a_out = na; b_out = nb;
+        if (Q.cg_all || N > Q.cg_above) {
+            // matrix-free: right-hand side, the start vector V0 = the current two-site block x_i x_{i+1} (what update_right /
+            // update_left hand to the next solve, dmrg.jl:311-316), CG, solution into Pb
+            WG_FOR(N) {
+                const int ab = (int)(e_ % na), cd = (int)(e_ / na);
+                double a = 0.0;
+                for (int z = 0; z < bz; ++z) a = fma(Gbi[ab + (long long)na * z], Hbi[z + (long long)bz * cd], a);
+                Pb[e_] = a;
+            }
+            double* cg = scr + Q.offCg;
+            double *xv = cg, *rv = cg + Q.cg_nmax, *pv = cg + 2 * Q.cg_nmax, *qv = cg + 3 * Q.cg_nmax, *Wv = cg + 4 * Q.cg_nmax;
+            const int rm = uni32((int)xr[i + 1]);
+            if (v0_swapped && n1 == n2) {
+                // after a LEFT move the reference builds the start vector with the two physical indices exchanged (update_left reshapes
+                // [alpha, J, i_k, gamma] with the index of site i+1 running faster than that of site i, dmrg.jl:331-334): restated as
+                // it is — V0[(j, al), (k, be)] = sum_ga x_i[k, al, ga] x_{i+1}[j, ga, be], one rl x rr x rm product per (j, k)
+                for (int j = 0; j < n1; ++j)
+                    for (int k = 0; k < n2; ++k)
+                        wg_gemm(rl, rr, rm, mkview(XC(i) + k, plain(n1), plain((long long)n1 * rl)), mkview(XC(i + 1) + j, plain(n2), plain((long long)n2 * rm)),
+                                mkview(xv + j + (long long)na * k, plain(n1), plain((long long)na * n2)), 1.0, 0.0, lds);
+            } else {
+                // V0[(j, al), (k, be)] = sum_ga x_i[j, al, ga] x_{i+1}[k, ga, be]: the current two-site block (b_mid / update_right)
+                wg_gemm(na, nb, rm, mkview(XC(i), plain(1), plain(na)), mkview(XC(i + 1), plain(n2), Idx{n2, 1, (long long)n2 * rm}),
+                        mkview(xv, plain(1), plain(na)), 1.0, 0.0, lds);
+            }
+            const int iters = wg_cg_two_site(na, nb, Rz, const_cast<double*>(Gi), const_cast<double*>(Hi), xv, Pb, rv, pv, qv, Wv, Q.cg_tol, Q.cg_maxiter, red, lds);
+            WG_FOR(N) Pb[e_] = xv[e_];
+            if (Q.cg_iters && tid == 0) Q.cg_iters[b] += iters;
+            __syncthreads();
+            return true;
+        }
         WG_FOR((long long)N * N) {
             const int row = (int)(e_ % N), col = (int)(e_ / N);
             const int ab = row % na, cd = row / na, ef = col % na, gh = col / na;
@@ -593,6 +693,7 @@ __global__ void __launch_bounds__(TTN_WG) k_mals_linsolve(MalsArgs Q) {
     const int per = mode == 0 ? 2 * (d - 1) : 2 * (d - 2);                 // windows visited by one sweep
     const int total = mode == 0 ? per : uni32(Q.nsweeps) * per + 1;
     const int rule = mode == 0 ? 1 : 2;
+    int prev_dir = 0;                                                      // direction of the move before this solve (start: none)
     for (int t = 0; t < total && !status; ++t) {
         int i, dir, rmax;
         if (mode == 0) { dir = t >= d - 1; i = dir ? 2 * (d - 1) - 1 - t : t; rmax = Q.rmax; }
@@ -600,7 +701,8 @@ __global__ void __launch_bounds__(TTN_WG) k_mals_linsolve(MalsArgs Q) {
         else { const int u = t % per; dir = u >= d - 2; i = dir ? 2 * (d - 2) - u : u; rmax = Q.rmax_sweep[t / per]; }
         i = uni32(i); dir = uni32(dir); rmax = uni32(rmax);
         int na, nb;
-        if (!ksolve(i, na, nb)) { status = 3; break; }
+        if (!ksolve(i, na, nb, prev_dir == 1)) { status = 3; break; }
+        prev_dir = dir;
         const int n2 = uni32(P.x.dims[i + 1]);
         double* xi = XC(i);
         double* xn = XC(i + 1);

@@ -1142,7 +1142,15 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
 
 // ---- mals_linsolve -----------------------------------------------------------------------------------------------
 // the two-site solvers: mode 0 = mals_linsolve, mode 1 = dmrg_linsolve (N = 2) with `plan` = the rank cap of every full sweep
-static int two_site_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t rmax, int mode, const std::vector<int64_t>& plan) {
+// Local solver of the two-site systems (dmrg.jl:92-97): conjugate gradients on the matrix-free operator if `it_solver` or the system
+// has more than `itslv_thresh` unknowns, dense LU otherwise.  The dense path holds K in memory and is limited to TTN_DENSE_LOCAL_MAX
+// unknowns; larger systems always take the matrix-free path.
+#define TTN_DENSE_LOCAL_MAX 2048
+struct LocalSolver { int it_solver = 0; int64_t itslv_thresh = TTN_DENSE_LOCAL_MAX; int64_t maxiter = 200; double tol = 1.0e-8; };
+static std::vector<int> g_cg_iters_host;       // total CG iterations per train of the last two-site solve (ttn_dmrg_cg_iterations)
+
+static int two_site_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t rmax, int mode, const std::vector<int64_t>& plan,
+                             const LocalSolver& ls = LocalSolver()) {
     NEED_INIT();
     if (!A || !b || !x0 || !x) return fail(TTN_ERR_ARG, "null handle");
     if (tol < 0.0 || rmax < 1) return fail(TTN_ERR_ARG, "bad tol / rmax");
@@ -1175,12 +1183,25 @@ static int two_site_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, d
             t2 = mx(t2, R[i + 1] * c[i + 1] * c[i + 1]);
         }
     }
-    if (Nmax > 2048) return fail(TTN_ERR_UNSUPPORTED, "ttn_mals_linsolve: two-site systems above 2048 unknowns (n_i cap_i n_{i+1} cap_{i+2}) are not supported; lower the capacity of x");
+    // mals_linsolve has no iterative branch in the reference (Hermitian(K) \ b, mals.jl:148-157): dense only
+    const long long dense_max = ls.it_solver ? 0 : std::min<long long>(TTN_DENSE_LOCAL_MAX, mode == 1 ? ls.itslv_thresh : TTN_DENSE_LOCAL_MAX);
+    const bool need_cg = mode == 1 && (ls.it_solver || Nmax > dense_max);
+    if (!need_cg && Nmax > TTN_DENSE_LOCAL_MAX) return fail(TTN_ERR_UNSUPPORTED, "ttn_mals_linsolve: two-site systems above 2048 unknowns (n_i cap_i n_{i+1} cap_{i+2}) are not supported; lower the capacity of x");
+    if (mmax > 256) return fail(TTN_ERR_UNSUPPORTED, "two-site solvers: n_i * capacity above 256 (ranks above 128 for n = 2) is not supported by the SVD core moves");
+    if (ls.maxiter < 1 || !(ls.tol >= 0.0)) return fail(TTN_ERR_ARG, "dmrg_linsolve: bad linsolv_maxiter / linsolv_tol");
     const long long pmax = std::min<long long>(mmax, 256), qmax = mmax;
+    long long Rzmax = 1;
+    for (int i = 0; i <= d; ++i) Rzmax = mx(Rzmax, R[i]);
     MalsArgs Q;
     memset(&Q, 0, sizeof(Q));
     AlsArgs& P = Q.L;
-    P.offK = cur; cur += Nmax * Nmax;
+    const long long Kdim = std::min<long long>(Nmax, dense_max);
+    P.offK = cur; cur += Kdim * Kdim;
+    if (need_cg) { Q.offCg = cur; Q.cg_nmax = Nmax; cur += (4 + Rzmax) * Nmax; }
+    Q.cg_all = ls.it_solver ? 1 : 0;
+    Q.cg_above = (int)std::min<long long>(dense_max, (1LL << 30));
+    Q.cg_maxiter = (int)std::min<int64_t>(ls.maxiter, 1 << 30);
+    Q.cg_tol = ls.tol;
     P.offPb = cur; cur += Nmax;
     P.offPiv = cur; cur += Nmax / 2 + 8;
     P.offT1 = cur; cur += t1;
@@ -1220,8 +1241,19 @@ static int two_site_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, d
     Q.rmax_final = Q.rmax;
     int64_t rtop = rmax;
     for (size_t s_ = 0; s_ < plan.size(); ++s_) { Q.rmax_sweep[s_] = (int)std::min<int64_t>(plan[s_], 1 << 30); rtop = std::max(rtop, plan[s_]); }
+    static int* d_cg_iters = nullptr; static int cg_cap = 0;
+    if (need_cg) {
+        if (cg_cap < batch) { if (d_cg_iters) hipFree(d_cg_iters); HIPCHK(hipMalloc((void**)&d_cg_iters, sizeof(int) * batch)); cg_cap = batch; }
+        HIPCHK(hipMemsetAsync(d_cg_iters, 0, sizeof(int) * batch, g_stream));
+        Q.cg_iters = d_cg_iters;
+    }
     hipLaunchKernelGGL(k_mals_linsolve, dim3(batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, Q);
     HIPCHK(hipGetLastError());
+    g_cg_iters_host.assign(batch, 0);
+    if (need_cg) {
+        HIPCHK(hipMemcpyAsync(g_cg_iters_host.data(), d_cg_iters, sizeof(int) * batch, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+    }
     for (int m = 1; m < d; ++m) x->bound[m] = std::min<int64_t>(x->cap[m], rtop);
     x->bound[0] = 1; x->bound[d] = 1;
     for (int bb = 0; bb < batch; ++bb)
@@ -1235,9 +1267,8 @@ int ttn_mals_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double t
     return two_site_linsolve(A, b, x0, x, tol, rmax, 0, {});
 }
 
-int ttn_dmrg_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t n_stages, const int64_t* sweep_schedule,
-                      const int64_t* rmax_schedule) {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+static int dmrg_linsolve_impl(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t n_stages, const int64_t* sweep_schedule,
+                              const int64_t* rmax_schedule, const LocalSolver& ls) {
     if (n_stages < 1 || !sweep_schedule || !rmax_schedule) return fail(TTN_ERR_ARG, "dmrg_linsolve: empty schedule");
     for (int64_t j = 0; j < n_stages; ++j) {
         // the reference's while-loop (dmrg.jl:421-426) only terminates for positive, strictly increasing stage ends
@@ -1252,7 +1283,31 @@ int ttn_dmrg_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double t
         plan.push_back(rmax_schedule[j]);
         if ((int64_t)plan.size() > TTN_DMRG_MAX_SWEEPS) return fail(TTN_ERR_UNSUPPORTED, "dmrg_linsolve: more than 32 sweeps in one call");
     }
-    return two_site_linsolve(A, b, x0, x, tol, rmax_schedule[n_stages - 1], 1, plan);
+    return two_site_linsolve(A, b, x0, x, tol, rmax_schedule[n_stages - 1], 1, plan, ls);
+}
+
+int ttn_dmrg_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t n_stages, const int64_t* sweep_schedule,
+                      const int64_t* rmax_schedule) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    LocalSolver ls;                      // dense LU up to TTN_DENSE_LOCAL_MAX unknowns, matrix-free CG (tol 1e-8) above
+    ls.tol = std::max(std::sqrt(std::max(tol, 0.0)), 1.0e-8);       // the reference's default linsolv_tol (dmrg.jl:394)
+    return dmrg_linsolve_impl(A, b, x0, x, tol, n_stages, sweep_schedule, rmax_schedule, ls);
+}
+
+int ttn_dmrg_linsolve_it(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, double tol, int64_t n_stages, const int64_t* sweep_schedule,
+                         const int64_t* rmax_schedule, int it_solver, int64_t linsolv_maxiter, double linsolv_tol, int64_t itslv_thresh) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (itslv_thresh < 0) return fail(TTN_ERR_ARG, "dmrg_linsolve: bad itslv_thresh");
+    LocalSolver ls;
+    ls.it_solver = it_solver ? 1 : 0; ls.itslv_thresh = itslv_thresh; ls.maxiter = linsolv_maxiter; ls.tol = linsolv_tol;
+    return dmrg_linsolve_impl(A, b, x0, x, tol, n_stages, sweep_schedule, rmax_schedule, ls);
+}
+
+int ttn_dmrg_cg_iterations(int64_t batch, int64_t* iters) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!iters || batch < 0 || (size_t)batch > g_cg_iters_host.size()) return fail(TTN_ERR_ARG, "ttn_dmrg_cg_iterations: no two-site solve of that batch size has run");
+    for (int64_t t = 0; t < batch; ++t) iters[t] = g_cg_iters_host[(size_t)t];
+    return TTN_OK;
 }
 
 // Failure codes of every dense kernel that wrote `h` since the last call (synchronises).  The codes are sticky on the device —

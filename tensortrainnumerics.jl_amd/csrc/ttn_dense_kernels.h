@@ -325,6 +325,9 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc_, double* lds) {
                 _Pragma("unroll") for (int u = 0; u < NUB; ++u) Bs0[bkk[u] * LDB + bc[u]] = bv0[u];
             }
             __syncthreads();
+#ifdef TTN_GEMM_PRIO
+            __builtin_amdgcn_s_setprio(TTN_GEMM_PRIO);       // experiment: the matrix-pipe phase ahead of a co-resident workgroup's latency-bound phase
+#endif
             for (int c = 0; c < nch; ++c) {
                 // The staging work of the other chunks is placed BETWEEN this wave's MFMA groups: an MFMA occupies the
                 // matrix pipe for 64 clk, so the VALU/LDS/global instructions issued behind it run under the MFMAs of
@@ -354,6 +357,9 @@ __device__ TTN_NI_GEMM void wg_gemm_impl(const GemmDesc* dsc_, double* lds) {
 #undef GEMM_MFMA_STEP
                 __syncthreads();
             }
+#ifdef TTN_GEMM_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #undef GEMM_FILL_TAB
 #undef GEMM_LOAD
 #undef GEMM_STORE
@@ -515,9 +521,10 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
         wg_gemm_small_impl(dsc, lds);
     } else if (shape_ok && (long long)k * wtight <= GEMM_LDS_DOUBLES) {
         wg_gemm_small_impl(dsc, lds);                    // pad = 0: tight leading dimensions
-    } else if (shape_ok && k <= 8 * (GEMM_LDS_DOUBLES / wtight)) {
+    } else if (shape_ok && A.c.q == 0 && B.r.q == 0 && k <= 8 * (GEMM_LDS_DOUBLES / wtight)) {
         // few output tiles but a long K: the tiled GEMM would keep most waves idle; run the one-shot kernel over
-        // K chunks, accumulating into C (plain-stride k index assumed only through the Views: chunks shift A.c / B.r)
+        // K chunks, accumulating into C.  Plain-stride k indices only: a chunk is addressed by shifting the operands' base pointers,
+        // which a two-level k index (the stacked H of the matrix-free two-site operator) does not allow — that takes the tiled form
         const int kcmax = (GEMM_LDS_DOUBLES / wtight) & ~3;
         const int nck = (k + kcmax - 1) / kcmax;
         const int kc = (((k + nck - 1) / nck) + 3) & ~3;                  // balanced chunks, multiples of 4

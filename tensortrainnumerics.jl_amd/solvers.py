@@ -457,32 +457,66 @@ def mals_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1
 # dmrg_linsolve, N = 2 (src/solvers/dmrg.jl:388-472) — the same persistent two-site kernel in its DMRG mode
 # ---------------------------------------------------------------------------------------------------------------------
 def dmrg_linsolve_(A: DeviceTTO, b: DeviceTT, x0: DeviceTT, x: DeviceTT, tol: float = 1.0e-12, sweep_schedule: Sequence[int] = (2,),
-                   rmax_schedule: Sequence[int] | None = None) -> DeviceTT:
-    """x_b = dmrg_linsolve(A, b_b, x0_b; N = 2, tol, sweep_schedule, rmax_schedule) for every train of the batch, local systems
-    solved densely (the reference's it_solver = false branch, dmrg.jl:173-175); x's capacity bounds the adapted ranks."""
+                   rmax_schedule: Sequence[int] | None = None, it_solver: bool = False, linsolv_maxiter: int = 200,
+                   linsolv_tol: float | None = None, itslv_thresh: int = 2048) -> DeviceTT:
+    """x_b = dmrg_linsolve(A, b_b, x0_b; N = 2, tol, sweep_schedule, rmax_schedule, it_solver, linsolv_maxiter, linsolv_tol,
+    itslv_thresh) for every train of the batch; x's capacity bounds the adapted ranks.  Local systems: dense LU (the reference's
+    it_solver = false branch, dmrg.jl:173-175) unless `it_solver` or the system has more than `itslv_thresh` unknowns — then
+    matrix-free conjugate gradients (dmrg.jl:99-171).  The defaults here (it_solver False, itslv_thresh 2048) solve to rounding
+    wherever the dense path reaches; the reference's own defaults are it_solver = True, itslv_thresh = 256."""
     if rmax_schedule is None:
         rmax_schedule = (math.isqrt(math.prod(x0.dims)),)                   # dmrg.jl:391
+    if linsolv_tol is None:
+        linsolv_tol = max(math.sqrt(tol), 1.0e-8)                           # dmrg.jl:394
     ss = [int(v) for v in sweep_schedule]
     rs = [int(min(v, 2 ** 30)) for v in rmax_schedule]
     if len(rs) < len(ss):
         raise _lib.TTNError("dmrg_linsolve: rmax_schedule is shorter than sweep_schedule")      # BoundsError in the reference
     n = len(ss)
     arr = (C.c_int64 * max(n, 1))
-    _lib.check(_lib.lib().ttn_dmrg_linsolve(A.h, b.h, x0.h, x.h, float(tol), n, arr(*ss) if n else None, arr(*rs[:n]) if n else None))
+    _lib.check(_lib.lib().ttn_dmrg_linsolve_it(A.h, b.h, x0.h, x.h, float(tol), n, arr(*ss) if n else None, arr(*rs[:n]) if n else None,
+                                               1 if it_solver else 0, int(linsolv_maxiter), float(linsolv_tol), int(itslv_thresh)))
     return x
 
 
+def dmrg_cg_iterations(batch: int):
+    """Total conjugate-gradient iterations per train of the last two-site solve (0 when every local system was solved densely)."""
+    out = (C.c_int64 * batch)()
+    _lib.check(_lib.lib().ttn_dmrg_cg_iterations(batch, out))
+    return [int(v) for v in out]
+
+
+def dmrg_capacity(dims, start_rks, rmax: int, dense_only: bool = False):
+    """Rank capacity of the result handle of dmrg_linsolve: the reference's buffer bounds min(rmax, prod(dims[:k]), prod(dims[k:]))
+    (dmrg.jl:411), at least the start ranks; the SVD core moves take n_i * rank up to 256.  dense_only: lowered until every
+    two-site system fits the dense solver (2048 unknowns) like mals_capacity."""
+    if dense_only:
+        return mals_capacity(dims, start_rks, rmax)
+    d = len(dims)
+    cap = [1] + [max(min(int(rmax), int(math.prod(dims[:k])), int(math.prod(dims[k:]))), int(start_rks[k])) for k in range(1, d)] + [1]
+    for k in range(d):
+        if dims[k] * max(cap[k], cap[k + 1]) > 256:
+            raise _lib.TTNError("dmrg_linsolve: n_k * rank above 256 is not supported (ranks up to 128 for n = 2)")
+    return cap
+
+
 def dmrg_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1.0e-12, sweep_schedule: Sequence[int] = (2,),
-                  rmax_schedule: Sequence[int] | None = None, N: int = 2) -> TTvector:
-    """Host-level form for one right-hand side."""
+                  rmax_schedule: Sequence[int] | None = None, N: int = 2, it_solver: bool = False, linsolv_maxiter: int = 200,
+                  linsolv_tol: float | None = None, itslv_thresh: int = 2048) -> TTvector:
+    """Host-level form for one right-hand side (same keywords as src/solvers/dmrg.jl:388-396; see dmrg_linsolve_ for the two
+    defaults that differ)."""
     if N != 2:
         raise _lib.TTNError("dmrg_linsolve: only the two-site scheme N = 2 is offered (single-site: als_linsolve)")
     if rmax_schedule is None:
         rmax_schedule = (math.isqrt(math.prod(tt_start.ttv_dims)),)
     dA = DeviceTTO(A)
     db, dx0 = DeviceTT.from_host(b), DeviceTT.from_host(tt_start)
-    dx = DeviceTT(tt_start.ttv_dims, mals_capacity(tt_start.ttv_dims, tt_start.ttv_rks, max(int(v) for v in rmax_schedule)))
-    dmrg_linsolve_(dA, db, dx0, dx, tol, sweep_schedule, rmax_schedule)
+    rtop = max(int(v) for v in rmax_schedule)
+    cap = dmrg_capacity(tt_start.ttv_dims, tt_start.ttv_rks, rtop)
+    if not it_solver and max(tt_start.ttv_dims[i] * cap[i] * tt_start.ttv_dims[i + 1] * cap[i + 2] for i in range(len(cap) - 2)) <= 2048:
+        cap = mals_capacity(tt_start.ttv_dims, tt_start.ttv_rks, rtop)
+    dx = DeviceTT(tt_start.ttv_dims, cap)
+    dmrg_linsolve_(dA, db, dx0, dx, tol, sweep_schedule, rmax_schedule, it_solver, linsolv_maxiter, linsolv_tol, itslv_thresh)
     D.compress_status(dx)
     dx.max_ranks()
     return dx.download(0)

@@ -113,3 +113,86 @@ def test_dmrg_errors(T):
         T.solvers.dmrg_linsolve(A, b, x0, N=1)
     with pytest.raises(T.TTNError):                            # singular two-site system
         T.solvers.dmrg_linsolve(to_product(O.tto_scale(0.0, O.id_tto(d))), b, x0)
+
+
+# ---- the matrix-free local solver (dmrg.jl:92-171: `it_solver || N > itslv_thresh` -> conjugate gradients) --------------------------
+# The CG iteration itself lives in KrylovKit (third party, not in the reference tree): the oracle restates its published recurrence
+# (O.cg_solve) on the reference's symmetrised operator and start vectors.  A converged CG solve agrees with the dense solve to
+# linsolv_tol * cond(K) whatever the rounding path, so the bar here is: ranks exact, iterate as a tensor 1e-7 relative against the
+# oracle's CG run with the same keywords, and against the DENSE device path to the solver tolerance.
+@pytest.mark.parametrize("d,r0,rb,shift,tol,sched,rmaxs,lt,seed", [
+    (6, 2, 2, 2.0, 1e-10, [2], [8], 1e-12, 0), (8, 2, 2, 3.0, 1e-8, [3], [8], 1e-12, 1), (8, 3, 2, 1.0, 1e-10, [2, 4], [3, 6], 1e-12, 2),
+    (10, 2, 3, 1.0, 1e-6, [2], [8], 1e-10, 3), (5, 1, 2, 2.0, 1e-10, [1, 2, 3], [2, 3, 4], 1e-13, 4), (9, 4, 2, 2.0, 1e-10, [2], [16], 1e-12, 5)])
+def test_dmrg_matrix_free_cg_vs_oracle_and_dense(T, d, r0, rb, shift, tol, sched, rmaxs, lt, seed):
+    rng = np.random.default_rng(100 + seed)
+    A = _spd(d, shift)
+    b = O.rand_tt((2,) * d, rb, rng)
+    x0 = O.rand_tt((2,) * d, r0, rng)
+    st = {}
+    ref = O.dmrg_linsolve(A, b, x0, tol=tol, sweep_schedule=sched, rmax_schedule=rmaxs, it_solver=True, linsolv_tol=lt, stats=st)
+    got = T.solvers.dmrg_linsolve(to_product(A), to_product(b), to_product(x0), tol=tol, sweep_schedule=sched, rmax_schedule=rmaxs,
+                                  it_solver=True, linsolv_tol=lt)
+    iters = T.solvers.dmrg_cg_iterations(1)[0]
+    assert iters > 0 and abs(iters - st["cg_iterations"]) <= max(4, st["cg_iterations"] // 10), (iters, st)
+    assert list(got.ttv_rks) == list(ref.ttv_rks)
+    assert list(got.ttv_ot) == list(ref.ttv_ot)
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-7
+    dense = T.solvers.dmrg_linsolve(to_product(A), to_product(b), to_product(x0), tol=tol, sweep_schedule=sched, rmax_schedule=rmaxs)
+    assert T.solvers.dmrg_cg_iterations(1)[0] == 0                     # (every system below 2048 unknowns: solved by LU)
+    assert list(dense.ttv_rks) == list(got.ttv_rks)
+    assert tt_rel_diff(to_oracle(got), to_oracle(dense)) <= 1e-7
+
+
+def test_dmrg_itslv_thresh_switches_per_system(T):
+    """itslv_thresh = 20: the windows at the ends of the chain (<= 16 unknowns) are solved densely, the inner ones by CG — the
+    reference's per-system switch (dmrg.jl:96).  Oracle with the same keywords."""
+    rng = np.random.default_rng(77)
+    d = 8
+    A = _spd(d, 2.0)
+    b = O.rand_tt((2,) * d, 2, rng)
+    x0 = O.rand_tt((2,) * d, 3, rng)
+    kw = dict(tol=1e-10, sweep_schedule=[2], rmax_schedule=[6], linsolv_tol=1e-12, itslv_thresh=20)
+    st = {}
+    ref = O.dmrg_linsolve(A, b, x0, stats=st, **kw)
+    got = T.solvers.dmrg_linsolve(to_product(A), to_product(b), to_product(x0), **kw)
+    assert 0 < st["cg_solves"] < 2 * (d - 2) + 1
+    assert list(got.ttv_rks) == list(ref.ttv_rks)
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-7
+
+
+def test_dmrg_cg_hits_maxiter_like_the_reference(T):
+    """linsolv_maxiter = 3: KrylovKit returns the current iterate (with a warning) and the sweep goes on; so does the device."""
+    rng = np.random.default_rng(78)
+    d = 7
+    A = _spd(d, 0.5)
+    b = O.rand_tt((2,) * d, 2, rng)
+    x0 = O.rand_tt((2,) * d, 2, rng)
+    kw = dict(tol=1e-10, sweep_schedule=[2], rmax_schedule=[4], it_solver=True, linsolv_tol=1e-14, linsolv_maxiter=3)
+    ref = O.dmrg_linsolve(A, b, x0, **kw)
+    got = T.solvers.dmrg_linsolve(to_product(A), to_product(b), to_product(x0), **kw)
+    assert list(got.ttv_rks) == list(ref.ttv_rks)
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-7
+
+
+def test_dmrg_large_local_systems_beyond_the_dense_limit(T):
+    """Rank-40 start train on 2 x 7 bits: two-site systems of 4 * 40 * 40 = 6400 unknowns (> 2048: only the matrix-free path can take
+    them; the dense path would need a 328 MB matrix per system).  Operator: the 2D Laplacian of examples/Laplace_pde.jl scaled by h^2
+    plus the identity (cond ~ 9: CG converges to linsolv_tol well inside maxiter, so the iterate is pinned)."""
+    rng = np.random.default_rng(79)
+    dd = 7
+    L1 = O.toeplitz_to_qtto(2.0, -1.0, -1.0, dd)
+    I1 = O.id_tto(dd)
+    kron = lambda P_, Q_: O.TToperator(P_.N + Q_.N, list(P_.tto_vec) + list(Q_.tto_vec), tuple(P_.tto_dims) + tuple(Q_.tto_dims),   # noqa: E731
+                                       list(P_.tto_rks[:-1]) + list(Q_.tto_rks), [0] * (P_.N + Q_.N))
+    A = O.tto_add(O.tto_add(kron(L1, I1), kron(I1, L1)), kron(I1, I1))
+    d = 2 * dd
+    b = O.rand_tt((2,) * d, 3, rng)
+    x0 = O.rand_tt((2,) * d, 40, rng)
+    assert max(4 * x0.ttv_rks[i] * x0.ttv_rks[i + 2] for i in range(d - 1)) == 6400
+    kw = dict(tol=1e-8, sweep_schedule=[2], rmax_schedule=[40], it_solver=True, linsolv_tol=1e-9)
+    st = {}
+    ref = O.dmrg_linsolve(A, b, x0, stats=st, **kw)
+    got = T.solvers.dmrg_linsolve(to_product(A), to_product(b), to_product(x0), **kw)
+    assert list(got.ttv_rks) == list(ref.ttv_rks), (got.ttv_rks, ref.ttv_rks)
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-7
+    assert abs(_resid(A, to_oracle(got), b) - _resid(A, ref, b)) <= 1e-7
