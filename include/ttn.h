@@ -169,6 +169,31 @@ int ttn_dmrg_linsolve_it(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, doubl
                          const int64_t* rmax_schedule, int it_solver, int64_t linsolv_maxiter, double linsolv_tol, int64_t itslv_thresh);
 int ttn_dmrg_cg_iterations(int64_t batch, int64_t* iters);
 
+/* --- TDVP local contractions (src/solvers/tdvp.jl:29-43, :205-208), batched, Float64 (cplx = 0) or ComplexF64
+ * (cplx = 1: interleaved re/im pairs, as Julia stores them).  Tensors are column-major in the layouts tdvp1sweep! / tdvp2sweep! hold
+ * them in — sites (l, s, r) = permutedims(ttv_vec[k], (2,1,3)), operator cores (a, s, b, s') = permutedims(tto_vec[k], (3,1,4,2))
+ * (:52-53) — `batch` of each back to back; the operator core(s) may be one shared tensor (m_shared != 0).
+ *   _applyH1_lsr      HAC[α,s,β]      = FL[α,a,α'] AC[α',s',β'] M[a,s,b,s'] FR[β',b,β]             FL (Dl,a,Dl)  AC (Dl,d,Dr)  M (a,d,b,d)  FR (Dr,b,Dr)
+ *   _applyH0          HC[α,β]         = FL[α,a,α'] C[α',β'] FR[β',a,β]                             FL (Dl,a,Dl)  C (Dl,Dr)     FR (Dr,a,Dr)
+ *   _update_left_env  FLnext[α,a,β]   = FL[α',a',β'] A[β',s',β] M[a',s,a,s'] conj(A[α',s,α])       A (Dl,d,Dr)  M (a_in,d,a_out,d)  FL (Dl,a_in,Dl) -> (Dr,a_out,Dr)
+ *   _update_right_env FRprev[α,a,β]   = A[α,s',α'] FR[α',a',β'] M[a,s,a',s'] conj(A[β,s,β'])       A (Dl,d,Dr)  M (a_out,d,a_in,d)  FR (Dr,a_in,Dr) -> (Dl,a_out,Dl)
+ *   _applyH2_lsr      HAAC[α,s1,s2,β] = FL[α,a,α'] AAC[α',s1',s2',β'] M1[a,s1,b,s1'] M2[b,s2,c,s2'] FR[β',c,β]
+ * Each is a chain of fp64 MFMA GEMMs over strided views of the arrays as they lie (no permuted copies); a complex product is four
+ * real ones.  The first five take DEVICE pointers (asynchronous on the library stream); ttn_tdvp_contract_f64 stages HOST arrays:
+ * op = 0 applyH1, 1 applyH0, 2 update_left_env, 3 update_right_env, 4 applyH2; dims7 = {Dl, d (d1), Dr, a, b, c, d2} with a = a_in,
+ * b = a_out for the environment updates; FL / FR / M1 / M2 that an op does not use are ignored (may be null); X = AC / C / A / AAC. */
+int ttn_tdvp_apply_h1(int cplx, int64_t batch, int64_t Dl, int64_t d, int64_t Dr, int64_t a, int64_t b, const double* FL, const double* AC,
+                      const double* M, const double* FR, double* HAC, int m_shared);
+int ttn_tdvp_apply_h0(int cplx, int64_t batch, int64_t Dl, int64_t Dr, int64_t a, const double* FL, const double* C, const double* FR, double* HC);
+int ttn_tdvp_update_left_env(int cplx, int64_t batch, int64_t Dl, int64_t d, int64_t Dr, int64_t a_in, int64_t a_out, const double* A, const double* M,
+                             const double* FL, double* FLnext, int m_shared);
+int ttn_tdvp_update_right_env(int cplx, int64_t batch, int64_t Dl, int64_t d, int64_t Dr, int64_t a_out, int64_t a_in, const double* A, const double* M,
+                              const double* FR, double* FRprev, int m_shared);
+int ttn_tdvp_apply_h2(int cplx, int64_t batch, int64_t Dl, int64_t d1, int64_t d2, int64_t Dr, int64_t a, int64_t b, int64_t c, const double* FL,
+                      const double* AAC, const double* M1, const double* M2, const double* FR, double* HAAC, int m_shared);
+int ttn_tdvp_contract_f64(int op, int cplx, int64_t batch, const int64_t* dims7, const double* FL, const double* FR, const double* X, const double* M1,
+                          const double* M2, double* out, int m_shared);
+
 /* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);
 

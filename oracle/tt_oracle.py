@@ -1095,6 +1095,49 @@ def dmrg_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1
 
 
 # --------------------------------------------------------------------------------------
+# TDVP local contractions — src/solvers/tdvp.jl:24-43, :205-208 (the @tensor index strings verbatim as einsum subscripts)
+# --------------------------------------------------------------------------------------
+def tdvp_to_lsr(A):
+    """_to_lsr / _to_slr: permutedims(A, (2, 1, 3))  (tdvp.jl:24-25)"""
+    return np.transpose(A, (1, 0, 2))
+
+
+def tdvp_mpo_to_asbs(M):
+    """_mpo_to_asbs: permutedims(M, (3, 1, 4, 2))  (tdvp.jl:27)"""
+    return np.transpose(M, (2, 0, 3, 1))
+
+
+def tdvp_dot3(X, Y):
+    """_dot3 = LinearAlgebra.dot(vec(X), vec(Y)): conjugates the FIRST argument  (tdvp.jl:29)"""
+    return np.vdot(np.reshape(X, -1, order="F"), np.reshape(Y, -1, order="F"))
+
+
+def tdvp_applyH1_lsr(AC, FL, FR, M):
+    """HAC[α,s,β] := FL[α,a,α′] * AC[α′,s′,β′] * M[a,s,b,s′] * FR[β′,b,β]  (tdvp.jl:29-31)"""
+    return np.einsum("xay,ytq,asbt,qbz->xsz", FL, AC, M, FR, optimize=True)
+
+
+def tdvp_applyH0(C, FL, FR):
+    """HC[α,β] := FL[α,a,α′] * C[α′,β′] * FR[β′,a,β]  (tdvp.jl:33-35)"""
+    return np.einsum("xay,yq,qaz->xz", FL, C, FR, optimize=True)
+
+
+def tdvp_update_left_env(A, M, FL):
+    """FLnext[α,a,β] := FL[α′,a′,β′] * A[β′,s′,β] * M[a′,s,a,s′] * conj(A[α′,s,α])  (tdvp.jl:37-39)"""
+    return np.einsum("xpq,qtb,psat,xsu->uab", FL, A, M, np.conj(A), optimize=True)
+
+
+def tdvp_update_right_env(A, M, FR):
+    """FRprev[α,a,β] := A[α,s′,α′] * FR[α′,a′,β′] * M[a,s,a′,s′] * conj(A[β,s,β′])  (tdvp.jl:41-43)"""
+    return np.einsum("xty,ypq,aspt,bsq->xab", A, FR, M, np.conj(A), optimize=True)
+
+
+def tdvp_applyH2_lsr(AAC, FL, FR, M1, M2):
+    """HAAC[α,s1,s2,β] := FL[α,a,α′] * AAC[α′,s1′,s2′,β′] * M1[a,s1,b,s1′] * M2[b,s2,c,s2′] * FR[β′,c,β]  (tdvp.jl:205-208)"""
+    return np.einsum("xay,ytuq,asbt,bvcu,qcz->xsvz", FL, AAC, M1, M2, FR, optimize=True)
+
+
+# --------------------------------------------------------------------------------------
 # Explicit time steppers (callers of the hot path) — src/solvers/euler.jl:76-97, :193-209
 # --------------------------------------------------------------------------------------
 def rk4_method(A: TToperator, u0: TTvector, steps, max_bond: int, normalize: bool = True) -> TTvector:

@@ -4,7 +4,7 @@ Host-side mirror of the reference interface (tt.py), input generators (construct
 device-resident batched handles (device.py) and the ctypes binding of the C ABI (_lib.py).
 The arithmetic lives in csrc/*.h, csrc/ttn_api.hip -> libttn_hip.so (hand-written HIP, gfx950).
 """
-from . import _lib, constructors, device, pipeline, qtt, shard, solvers, tt
+from . import _lib, constructors, device, pipeline, qtt, shard, solvers, tdvp, tt
 from ._lib import TTNError, build, ensure_init, finalize
 from .constructors import (Delta, id_tto, portable_randn, qtt_cos, qtt_exp, qtt_sin, qtt_to_vector, rand_tt, shift,
                            toeplitz_to_qtto, zeros_tt, zeros_tto)

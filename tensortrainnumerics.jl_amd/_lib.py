@@ -74,6 +74,12 @@ SIGNATURES = {
     "ttn_dmrg_linsolve": (C.c_int, [handle, handle, handle, handle, C.c_double, i64, p_i64, p_i64]),
     "ttn_dmrg_linsolve_it": (C.c_int, [handle, handle, handle, handle, C.c_double, i64, p_i64, p_i64, C.c_int, i64, C.c_double, i64]),
     "ttn_dmrg_cg_iterations": (C.c_int, [i64, p_i64]),
+    "ttn_tdvp_apply_h1": (C.c_int, [C.c_int, i64, i64, i64, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ttn_tdvp_apply_h0": (C.c_int, [C.c_int, i64, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ttn_tdvp_update_left_env": (C.c_int, [C.c_int, i64, i64, i64, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ttn_tdvp_update_right_env": (C.c_int, [C.c_int, i64, i64, i64, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ttn_tdvp_apply_h2": (C.c_int, [C.c_int, i64, i64, i64, i64, i64, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ttn_tdvp_contract_f64": (C.c_int, [C.c_int, C.c_int, i64, p_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ttn_selftest_eig128": (C.c_int, [C.c_void_p, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ttn_add": (C.c_int, [handle, handle, handle]),
     "ttn_scale": (C.c_int, [C.c_double, handle, handle]),
@@ -113,7 +119,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         newest = max(os.path.getmtime(s) for s in srcs)
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed",
            "-o", LIB_PATH, os.path.join(CSRC, "ttn_api.hip"), os.path.join(CSRC, "ttn_wg512.hip")]
     if verbose:
         print(" ".join(cmd))

@@ -7,6 +7,7 @@
 #include "ttn_hsvd_kernels.h"
 #include "ttn_als_kernels.h"
 #include "ttn_eig_kernels.h"
+#include "ttn_tdvp_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -172,6 +173,7 @@ int ttn_init(int device) {
                                (int)(sizeof(double) * GEMM_LDS_TOTAL)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(COMPRESS_LDS_BYTES)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tdvp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TDVP_LDS_BYTES));
     { const int rc512 = ttn_wg512_init(); if (rc512) return hipfail((hipError_t)rc512, "ttn_wg512_init"); }
     static_assert(sizeof(CompressArgs) > 0, "");
     if (ttn_wg512_compress_args_bytes() != sizeof(CompressArgs)) return fail(TTN_ERR_ARG, "ttn_init: the two kernel builds disagree on CompressArgs");
@@ -1552,6 +1554,97 @@ int ttn_sv_get(ttn_tt_t h, int64_t b, int64_t step, double* out, int64_t cap, in
 }
 
 // ---- stateless host-pointer entry points ----------------------------------------------------------
+// ---- TDVP local contractions (src/solvers/tdvp.jl:29-43, :205-208), batched, real or complex -------------------------------------
+// Device-pointer forms: every tensor is an array of `batch` column-major tensors laid out back to back (stride = its size; M may be
+// shared by the batch: m_shared != 0).  The host forms (…_f64) stage host arrays of the same layout through the device.
+static int tdvp_launch(int op, int cplx, int64_t batch, int64_t Dl, int64_t d, int64_t Dr, int64_t a, int64_t b, int64_t c, int64_t d2,
+                       const double* FL, const double* FR, const double* X, const double* M1, const double* M2, double* out, int m_shared,
+                       bool host) {
+    NEED_INIT();
+    if (batch < 1 || Dl < 1 || d < 1 || Dr < 1 || a < 1 || b < 1 || c < 1 || d2 < 1 || !X || !out) return fail(TTN_ERR_ARG, "tdvp: bad argument");
+    const int64_t lim = 1 << 20;
+    if (Dl > 4096 || Dr > 4096 || d > 64 || d2 > 64 || a > 64 || b > 64 || c > 64 || Dl * Dr * d * d2 * std::max({a, b, c}) > (lim << 6))
+        return fail(TTN_ERR_UNSUPPORTED, "tdvp: tensor too large");
+    const long long es = cplx ? 2 : 1;
+    long long nFL = 0, nFR = 0, nX = 0, nM1 = 0, nM2 = 0, nOut = 0, w1 = 0, w2 = 0;
+    switch (op) {
+    case 0: nFL = Dl * a * Dl; nFR = Dr * b * Dr; nX = Dl * d * Dr; nM1 = a * d * b * d; nOut = Dl * d * Dr; w1 = Dl * a * d * Dr; w2 = Dl * d * Dr * b; break;
+    case 1: nFL = Dl * a * Dl; nFR = Dr * a * Dr; nX = Dl * Dr; nOut = Dl * Dr; w1 = Dl * a * Dr; w2 = 1; break;
+    case 2: nFL = Dl * a * Dl; nX = Dl * d * Dr; nM1 = a * d * b * d; nOut = Dr * b * Dr; w1 = Dl * a * d * Dr; w2 = Dl * d * b * Dr; break;
+    case 3: nFR = Dr * a * Dr; nX = Dl * d * Dr; nM1 = b * d * a * d; nOut = Dl * b * Dl; w1 = Dl * d * a * Dr; w2 = Dl * b * d * Dr; break;
+    case 4: nFL = Dl * a * Dl; nFR = Dr * c * Dr; nX = Dl * d * d2 * Dr; nM1 = a * d * b * d; nM2 = b * d2 * c * d2; nOut = Dl * d * d2 * Dr;
+            w1 = Dl * d * d2 * Dr * std::max(a, c); w2 = Dl * d * b * d2 * Dr; break;
+    default: return fail(TTN_ERR_ARG, "tdvp: unknown contraction");
+    }
+    if ((nFL && !FL) || (nFR && !FR) || (nM1 && !M1) || (nM2 && !M2)) return fail(TTN_ERR_ARG, "tdvp: null tensor");
+    const long long mb = m_shared ? 1 : batch;
+    const size_t work_d = (size_t)(w1 + w2) * es * batch;
+    const size_t stage_d = host ? (size_t)es * ((nFL + nFR + nX + nOut) * batch + (nM1 + nM2) * mb) : 0;
+    int rc = ensure_scratch(sizeof(double) * (work_d + stage_d));
+    if (rc) return rc;
+    double* base = (double*)g_scratch;
+    TdvpArgs P;
+    memset(&P, 0, sizeof(P));
+    P.op = op; P.cplx = cplx;
+    P.Dl = (int)Dl; P.d = (int)d; P.Dr = (int)Dr; P.a = (int)a; P.b = (int)b; P.c = (int)c; P.d2 = (int)d2;
+    P.work = base; P.sWork = w1 + w2; P.w2off = w1;
+    P.sFL = nFL; P.sFR = nFR; P.sX = nX; P.sOut = nOut; P.sM1 = m_shared ? 0 : nM1; P.sM2 = m_shared ? 0 : nM2;
+    double* dout = out;
+    if (host) {
+        double* q = base + work_d;
+        auto stage = [&](const double* src, long long n, long long cnt) -> const double* {
+            if (!n) return nullptr;
+            double* dst = q; q += (size_t)n * es * cnt;
+            hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n * es * cnt, hipMemcpyHostToDevice, g_stream);
+            return dst;
+        };
+        P.FL = stage(FL, nFL, batch); P.FR = stage(FR, nFR, batch); P.X = stage(X, nX, batch);
+        P.M1 = stage(M1, nM1, mb); P.M2 = stage(M2, nM2, mb);
+        dout = q;
+    } else { P.FL = FL; P.FR = FR; P.X = X; P.M1 = M1; P.M2 = M2; }
+    P.out = dout;
+    hipLaunchKernelGGL(k_tdvp, dim3((unsigned)batch), dim3(TTN_WG), TDVP_LDS_BYTES, g_stream, P);
+    HIPCHK(hipGetLastError());
+    if (host) {
+        HIPCHK(hipMemcpyAsync(out, dout, sizeof(double) * (size_t)nOut * es * batch, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+    }
+    return TTN_OK;
+}
+
+int ttn_tdvp_apply_h1(int cplx, int64_t batch, int64_t Dl, int64_t d, int64_t Dr, int64_t a, int64_t b, const double* FL, const double* AC,
+                      const double* M, const double* FR, double* HAC, int m_shared) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return tdvp_launch(0, cplx, batch, Dl, d, Dr, a, b, 1, 1, FL, FR, AC, M, nullptr, HAC, m_shared, false);
+}
+int ttn_tdvp_apply_h0(int cplx, int64_t batch, int64_t Dl, int64_t Dr, int64_t a, const double* FL, const double* C, const double* FR, double* HC) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return tdvp_launch(1, cplx, batch, Dl, 1, Dr, a, 1, 1, 1, FL, FR, C, nullptr, nullptr, HC, 0, false);
+}
+int ttn_tdvp_update_left_env(int cplx, int64_t batch, int64_t Dl, int64_t d, int64_t Dr, int64_t a_in, int64_t a_out, const double* A, const double* M,
+                             const double* FL, double* FLnext, int m_shared) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return tdvp_launch(2, cplx, batch, Dl, d, Dr, a_in, a_out, 1, 1, FL, nullptr, A, M, nullptr, FLnext, m_shared, false);
+}
+int ttn_tdvp_update_right_env(int cplx, int64_t batch, int64_t Dl, int64_t d, int64_t Dr, int64_t a_out, int64_t a_in, const double* A, const double* M,
+                              const double* FR, double* FRprev, int m_shared) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return tdvp_launch(3, cplx, batch, Dl, d, Dr, a_in, a_out, 1, 1, nullptr, FR, A, M, nullptr, FRprev, m_shared, false);
+}
+int ttn_tdvp_apply_h2(int cplx, int64_t batch, int64_t Dl, int64_t d1, int64_t d2, int64_t Dr, int64_t a, int64_t b, int64_t c, const double* FL,
+                      const double* AAC, const double* M1, const double* M2, const double* FR, double* HAAC, int m_shared) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return tdvp_launch(4, cplx, batch, Dl, d1, Dr, a, b, c, d2, FL, FR, AAC, M1, M2, HAAC, m_shared, false);
+}
+// host-array forms (what a `ccall` from tdvp1sweep! / tdvp2sweep! binds): op = 0 applyH1, 1 applyH0, 2 update_left_env,
+// 3 update_right_env, 4 applyH2; dims = {Dl, d (d1), Dr, a, b, c, d2} with the meaning of the device forms above
+int ttn_tdvp_contract_f64(int op, int cplx, int64_t batch, const int64_t* dims7, const double* FL, const double* FR, const double* X, const double* M1,
+                          const double* M2, double* out, int m_shared) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!dims7) return fail(TTN_ERR_ARG, "tdvp: null dims");
+    return tdvp_launch(op, cplx, batch, dims7[0], dims7[1], dims7[2], dims7[3], dims7[4], dims7[5], dims7[6], FL, FR, X, M1, M2, out, m_shared, true);
+}
+
 namespace {
 struct TmpTT {
     ttn_tt_t h = nullptr;

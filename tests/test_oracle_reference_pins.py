@@ -457,3 +457,92 @@ def test_dmrg_linsolve_reference_assertions():
     # the two-site schemes agree where both converge: mals after its sweep, dmrg after one sweep + closing step
     xm = O.mals_linsolve(A, b, x0, tol=1e-14, rmax=64)
     assert np.max(np.abs(O.qtt_to_vector(xm) - dense)) <= 1e-11 * np.max(np.abs(dense))
+
+
+# ---- TDVP local contractions: the reference's own known-answer tests (explicit loop nests), test/test_tdvp.jl:58-135, :206-226 ----------
+def _crandn(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+def test_tdvp_layout_helpers_like_reference():
+    rng = np.random.default_rng(42)
+    A = rng.standard_normal((3, 4, 5))                                   # test_tdvp.jl:47-60
+    assert O.tdvp_to_lsr(A).shape == (4, 3, 5)
+    assert np.array_equal(O.tdvp_to_lsr(O.tdvp_to_lsr(A)), A)
+    M = rng.standard_normal((2, 3, 4, 5))                                # (s_out, s_in, a, b)   :63-68
+    M2 = O.tdvp_mpo_to_asbs(M)
+    assert M2.shape == (4, 2, 5, 3) and np.array_equal(np.transpose(M2, (1, 3, 0, 2)), M)
+    X, Y = _crandn(rng, 2, 3, 4), _crandn(rng, 2, 3, 4)                  # :70-76
+    assert np.isclose(O.tdvp_dot3(X, Y), np.sum(np.conj(X.ravel(order="F")) * Y.ravel(order="F")), rtol=1e-12, atol=1e-12)
+
+
+def test_tdvp_applyH1_known_answer():
+    """test_tdvp.jl:78-97: explicit five-deep loop."""
+    rng = np.random.default_rng(43)
+    Dl, d_in, d_out, Dr, a, b = 2, 3, 3, 2, 2, 2
+    AC, FL, FR, M = _crandn(rng, Dl, d_in, Dr), _crandn(rng, Dl, a, Dl), _crandn(rng, Dr, b, Dr), _crandn(rng, a, d_out, b, d_in)
+    ref = np.zeros((Dl, d_out, Dr), dtype=complex)
+    for al in range(Dl):
+        for s in range(d_out):
+            for be in range(Dr):
+                z = 0.0
+                for ap in range(Dl):
+                    for sp in range(d_in):
+                        for bp in range(Dr):
+                            for ai in range(a):
+                                for bi in range(b):
+                                    z += FL[al, ai, ap] * AC[ap, sp, bp] * M[ai, s, bi, sp] * FR[bp, bi, be]
+                ref[al, s, be] = z
+    assert np.allclose(O.tdvp_applyH1_lsr(AC, FL, FR, M), ref, rtol=1e-12, atol=1e-12)
+
+
+def test_tdvp_applyH0_known_answer():
+    """test_tdvp.jl:99-117."""
+    rng = np.random.default_rng(44)
+    Dl, Dr, a = 3, 2, 4
+    C, FL, FR = _crandn(rng, Dl, Dr), _crandn(rng, Dl, a, Dl), _crandn(rng, Dr, a, Dr)
+    ref = np.zeros((Dl, Dr), dtype=complex)
+    for al in range(Dl):
+        for be in range(Dr):
+            ref[al, be] = sum(FL[al, ai, ap] * C[ap, bp] * FR[bp, ai, be] for ap in range(Dl) for ai in range(a) for bp in range(Dr))
+    assert np.allclose(O.tdvp_applyH0(C, FL, FR), ref, rtol=1e-12, atol=1e-12)
+
+
+def test_tdvp_env_updates_shapes_and_loops():
+    """test_tdvp.jl:119-135 asserts the shapes; the values are checked here against the index strings of tdvp.jl:37-43 written as loops."""
+    rng = np.random.default_rng(45)
+    Dl, d, Dr, a_in, a_out = 2, 3, 4, 2, 5
+    A, FL, FR = _crandn(rng, Dl, d, Dr), _crandn(rng, Dl, a_in, Dl), _crandn(rng, Dr, a_in, Dr)
+    M_L, M_R = _crandn(rng, a_in, d, a_out, d), _crandn(rng, a_out, d, a_in, d)
+    FLn, FRp = O.tdvp_update_left_env(A, M_L, FL), O.tdvp_update_right_env(A, M_R, FR)
+    assert FLn.shape == (Dr, a_out, Dr) and FRp.shape == (Dl, a_out, Dl)
+    ref = np.zeros_like(FLn)
+    for al in range(Dr):
+        for ao in range(a_out):
+            for be in range(Dr):
+                ref[al, ao, be] = sum(FL[x, ap, y] * A[y, sp, be] * M_L[ap, s, ao, sp] * np.conj(A[x, s, al])
+                                      for x in range(Dl) for ap in range(a_in) for y in range(Dl) for sp in range(d) for s in range(d))
+    assert np.allclose(FLn, ref, rtol=1e-12, atol=1e-12)
+    ref = np.zeros_like(FRp)
+    for al in range(Dl):
+        for ao in range(a_out):
+            for be in range(Dl):
+                ref[al, ao, be] = sum(A[al, sp, x] * FR[x, ap, y] * M_R[ao, s, ap, sp] * np.conj(A[be, s, y])
+                                      for x in range(Dr) for ap in range(a_in) for y in range(Dr) for sp in range(d) for s in range(d))
+    assert np.allclose(FRp, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_tdvp_applyH2_equals_two_site_loop():
+    rng = np.random.default_rng(46)
+    Dl, d1, d2, Dr, a, b, c = 2, 2, 3, 2, 2, 3, 2
+    AAC, FL, FR = _crandn(rng, Dl, d1, d2, Dr), _crandn(rng, Dl, a, Dl), _crandn(rng, Dr, c, Dr)
+    M1, M2 = _crandn(rng, a, d1, b, d1), _crandn(rng, b, d2, c, d2)
+    ref = np.zeros((Dl, d1, d2, Dr), dtype=complex)
+    for al in range(Dl):
+        for s1 in range(d1):
+            for s2 in range(d2):
+                for be in range(Dr):
+                    ref[al, s1, s2, be] = sum(FL[al, ai, ap] * AAC[ap, t1, t2, bp] * M1[ai, s1, bi, t1] * M2[bi, s2, ci, t2] * FR[bp, ci, be]
+                                              for ai in range(a) for ap in range(Dl) for t1 in range(d1) for t2 in range(d2)
+                                              for bp in range(Dr) for bi in range(b) for ci in range(c))
+    assert np.allclose(O.tdvp_applyH2_lsr(AAC, FL, FR, M1, M2), ref, rtol=1e-12, atol=1e-12)
