@@ -112,6 +112,14 @@ int ttn_bond_truncate(ttn_tt_t psi, int64_t k, int64_t max_bond, double truncerr
  * [batch][dims[k]*bound_left*bound_right] plus its two ranks [batch][2] (device pointers, e.g. of the tensor handed to
  * ncclSend/ncclRecv); import sets the host-side rank bounds the sender reports. */
 int ttn_sweep(ttn_tt_t psi, int64_t k_first, int64_t k_last, int64_t max_bond, double truncerr);
+/* The fused form for a segment: ttn_apply_begin gives y the ranks of A*x (no core is written); a boundary core may then be imported
+ * into y (ttn_tt_core_import); ttn_apply_sweep runs ONE L->R pass over the bonds k_first <= ... <= k_last with the cores right of
+ * the moving front still virtual (built from A and x inside the bond step, like ttn_apply_compress) — every core of the range is
+ * real afterwards.  first_core_real != 0: core k_first was imported and is used as it is; 0: it is written out first.
+ * ttn_stream_handle: the hipStream_t all calls are enqueued on, for event-based ordering against the caller's own streams. */
+int ttn_apply_begin(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y);
+int ttn_apply_sweep(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t k_first, int64_t k_last, int64_t max_bond, double truncerr, int first_core_real);
+int ttn_stream_handle(void** stream);
 int ttn_tt_core_extent(ttn_tt_t h, int64_t k, int64_t* doubles_per_train, int64_t* bound_left, int64_t* bound_right);
 int ttn_tt_core_export(ttn_tt_t h, int64_t k, double* dev_buf, int64_t* dev_rks2);
 int ttn_tt_core_import(ttn_tt_t h, int64_t k, const double* dev_buf, const int64_t* dev_rks2, int64_t bound_left, int64_t bound_right);

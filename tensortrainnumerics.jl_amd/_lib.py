@@ -60,6 +60,9 @@ SIGNATURES = {
     "ttn_bond_truncate": (C.c_int, [handle, i64, i64, C.c_double]),
     "ttn_apply_compress": (C.c_int, [handle, handle, handle, i64, C.c_double, i64]),
     "ttn_sweep": (C.c_int, [handle, i64, i64, i64, C.c_double]),
+    "ttn_apply_begin": (C.c_int, [handle, handle, handle]),
+    "ttn_apply_sweep": (C.c_int, [handle, handle, handle, i64, i64, i64, C.c_double, C.c_int]),
+    "ttn_stream_handle": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ttn_tt_core_extent": (C.c_int, [handle, i64, p_i64, p_i64, p_i64]),
     "ttn_tt_core_export": (C.c_int, [handle, i64, C.c_void_p, C.c_void_p]),
     "ttn_tt_core_import": (C.c_int, [handle, i64, C.c_void_p, C.c_void_p, i64, i64]),

@@ -706,7 +706,7 @@ static int compress_precheck(ttn_tt_t psi, const std::vector<int64_t>& bound, in
 }
 
 static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, double truncerr, int64_t sweeps,
-                           int64_t k_first = 0, int64_t k_last = 0, ttn_tto_t fuseA = nullptr, ttn_tt_t fusex = nullptr) {
+                           int64_t k_first = 0, int64_t k_last = 0, ttn_tto_t fuseA = nullptr, ttn_tt_t fusex = nullptr, int fused_first_real = 0) {
     const int d = psi->d;
     if (d < 2 && k_single == 0) return TTN_OK;
     std::vector<int64_t> fin;
@@ -738,6 +738,7 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     P.sweep_stats = psi->d_status + psi->batch;
     P.rank_rule = 0;
     P.fused = (fuseA && fusex) ? 1 : 0;
+    P.fused_first_real = fused_first_real;
     if (P.fused) { P.op = fuseA->dev(); P.x = fusex->dev(); }
     else { memset(&P.op, 0, sizeof(P.op)); memset(&P.x, 0, sizeof(P.x)); }
     P.prof = nullptr;
@@ -861,6 +862,44 @@ int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, do
     y->bound = yb;
     std::fill(y->ot.begin(), y->ot.end(), 0);
     return launch_compress(y, 0, max_bond, truncerr, sweeps, 0, 0, A, x);
+}
+
+// ---- fused apply for core-wise sharded chains: the product's ranks first, then ONE L->R pass over a bond range whose right cores
+// are still virtual.  Between the two calls a boundary core may be imported into y (ttn_tt_core_import).
+int ttn_apply_begin(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!A || !x || !y) return fail(TTN_ERR_ARG, "null handle");
+    if (!same_dims(A->dims, x->dims) || !same_dims(x->dims, y->dims)) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    if (x->batch != y->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
+    if (x == y) return fail(TTN_ERR_ARG, "ttn_apply_begin: output must not alias the input");
+    const int d = x->d;
+    for (int m = 0; m <= d; ++m) if (y->cap[m] < A->rks[m] * x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_apply: destination capacity too small");
+    hipLaunchKernelGGL(k_ranks_mul_op, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), A->dev(), x->dev());
+    HIPCHK(hipGetLastError());
+    for (int m = 0; m <= d; ++m) y->bound[m] = A->rks[m] * x->bound[m];
+    std::fill(y->ot.begin(), y->ot.end(), 0);
+    return TTN_OK;
+}
+
+int ttn_apply_sweep(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t k_first, int64_t k_last, int64_t max_bond, double truncerr, int first_core_real) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!A || !x || !y) return fail(TTN_ERR_ARG, "null handle");
+    if (!same_dims(A->dims, x->dims) || !same_dims(x->dims, y->dims) || x->batch != y->batch) return fail(TTN_ERR_DIMS, "Incompatible dimensions");
+    if (k_first < 1 || k_first >= y->d || k_last < k_first || k_last >= y->d) return fail(TTN_ERR_BOND_INDEX, "ttn_apply_sweep: need 1 <= k_first <= k_last <= N-1 (one L->R pass)");
+    if (max_bond < 1) return fail(TTN_ERR_ARG, "max_bond must be >= 1");
+    return launch_compress(y, -1, max_bond, truncerr, 1, k_first - 1, k_last - 1, A, x, first_core_real ? 1 : 0);
+}
+
+// The HIP stream every call of this library is enqueued on (hipStream_t): lets a caller order its own streams against the
+// library's work with events instead of host synchronisation (the boundary-core hand-offs of pipeline.py)
+int ttn_stream_handle(void** stream) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!stream) return fail(TTN_ERR_ARG, "null pointer");
+    *stream = (void*)g_stream;
+    return TTN_OK;
 }
 
 // ---- site-swap chains: hadamard_ttm and reorder -----------------------------------------------------

@@ -10,7 +10,9 @@
 // Register budget of the dense kernels: 128 VGPRs per lane in both builds.  1024 threads = 4 waves per SIMD already imply it; the
 // 512-thread build asks for 4 waves per SIMD explicitly (second launch-bounds argument = minimum waves per execution unit), i.e.
 // two resident workgroups per CU — without it the compiler would take up to 256 registers and one workgroup would own the CU.
-#if TTN_WG == 512
+#if TTN_WG == 512 && defined(TTN_WG512_ONE_PER_CU)
+#define TTN_KERNEL_BOUNDS __launch_bounds__(512)        // experiment: up to 256 VGPRs, no spills, one workgroup per CU
+#elif TTN_WG == 512
 #define TTN_KERNEL_BOUNDS __launch_bounds__(512, 4)
 #else
 #define TTN_KERNEL_BOUNDS __launch_bounds__(TTN_WG)

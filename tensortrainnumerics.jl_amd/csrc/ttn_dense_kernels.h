@@ -1631,6 +1631,8 @@ struct CompressArgs {
     TTDev x;
     int rank_rule;         // 0: relative tail norm (_svdtrunc, tt_cross_interpolation.jl:149-166); 1: count(s > truncerr * s[1]), at least 1
                            //    (_swap_adjacent_sites, src/qtt_tools.jl:680-685)
+    int fused_first_real;  // fused bond range (k_single < 0, ascending): the left core of the first bond is already real (a boundary core
+                           // imported from the left neighbour of a core-wise sharded chain); otherwise it is written out first
     int* next_train;       // null: one workgroup per train (grid = batch).  Else a device counter (zeroed before the launch): the grid is
                            // PERSISTENT — workgroup w starts with train w and then pulls train gridDim.x + atomicAdd(next_train, 1)
                            // until the batch is exhausted (dynamic balancing of the data-dependent sweep counts, scratch per slot)
@@ -2369,12 +2371,14 @@ __global__ void TTN_KERNEL_BOUNDS k_compress(CompressArgs P) {
     while (b < P.tt.batch) {
         if (threadIdx.x == 0) P.sweep_stats[b] = 0;        // (P.status is sticky: only failures are stored, the host clears on read)
         __syncthreads();
-        if (P.fused) wg_materialize_core(P, b, 0);
+        // fused apply: the left core of the first bond is written out (unless it was imported), every core to its right stays
+        // virtual until the front of the first L->R pass reaches it
+        if (P.fused && !(P.k_single < 0 && P.fused_first_real)) wg_materialize_core(P, b, (P.k_single < 0) ? P.k_first : 0);
         for (int step = 0; step < nsteps; ++step) {
             int k;
             bool virt = false;
             if (P.k_single > 0) k = P.k_single - 1;                                  // _tt_bond_truncate!
-            else if (P.k_single < 0) k = (P.k_first <= P.k_last) ? P.k_first + step : P.k_first - step;     // ttn_sweep
+            else if (P.k_single < 0) { k = (P.k_first <= P.k_last) ? P.k_first + step : P.k_first - step; virt = P.fused != 0; }   // ttn_sweep / ttn_apply_sweep
             else {                                                                   // tt_compress!: L->R then R->L per sweep
                 const int i = step % per_sweep;
                 k = (i < d - 1) ? i : per_sweep - 1 - i;

@@ -53,9 +53,17 @@ class DeviceBackend:
     name = "hip"
 
     def __init__(self):
+        import ctypes as C
         import torch
         from . import _lib, device
         self.torch, self._lib, self.D = torch, _lib, device
+        _lib.ensure_init()
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ttn_stream_handle(C.byref(h)))
+        # the library's HIP stream as a torch stream: the hand-offs are ordered against it with EVENTS (wait_stream), the host
+        # never blocks between a sweep and the send that follows it
+        self.lib_stream = torch.cuda.ExternalStream(h.value)
+        self._keep = []                            # tensors the library stream still reads (released at flush)
 
     def prepare(self, A_cores, A_rks, x_trains, dims):
         """Upload the extended segment of the operator and of a micro-batch of trains (list of per-train core lists);
@@ -74,10 +82,20 @@ class DeviceBackend:
         return dA, dx, dy
 
     def apply_prepared(self, prep):
-        """y_ext = A_ext * x_ext on the device; returns the DeviceTT the sweeps then work on."""
+        """y_ext = A_ext * x_ext, VIRTUALLY: y only receives the product's ranks (ttn_apply_begin); the cores are built inside
+        the bond steps of lr_sweep (fused apply, as in ttn_apply_compress).  Returns the DeviceTT the sweeps work on."""
         dA, dx, dy = prep
-        self.D.apply(dA, dx, dy)
+        self._lib.check(self._lib.lib().ttn_apply_begin(dA.h, dx.h, dy.h))
+        dy._fuse = (dA, dx)
         return dy
+
+    def lr_sweep(self, seg, n_ext: int, max_bond: int, truncerr: float, first_real: bool):
+        """The L->R pass over all bonds of the extended segment with the fused apply; first_real: core 0 was imported."""
+        dA, dx = seg._fuse
+        if n_ext >= 2:
+            self._lib.check(self._lib.lib().ttn_apply_sweep(dA.h, dx.h, seg.h, 1, n_ext - 1, int(max_bond), float(truncerr), 1 if first_real else 0))
+        elif not first_real:
+            self.D.apply(dA, dx, seg)              # a one-core segment with nothing to its left: the core itself
 
     def sweep(self, seg, k_first: int, k_last: int, max_bond: int, truncerr: float):
         self._lib.check(self._lib.lib().ttn_sweep(seg.h, int(k_first) + 1, int(k_last) + 1, int(max_bond), float(truncerr)))
@@ -90,16 +108,23 @@ class DeviceBackend:
         data = self.torch.empty((seg.batch, n.value), dtype=self.torch.float64, device=dev)
         rks = self.torch.empty((seg.batch, 2), dtype=self.torch.int64, device=dev)
         self._lib.check(self._lib.lib().ttn_tt_core_export(seg.h, k + 1, data.data_ptr(), rks.data_ptr()))
-        self.D.sync()                              # the copy ran on the library's stream; the transport uses torch's
+        # the copy runs on the library's stream; whatever the transport does with the tensors on torch's stream waits for it
+        # on the DEVICE (an event), the host goes on
+        self.torch.cuda.current_stream().wait_stream(self.lib_stream)
         return data, rks, int(bl.value), int(br.value)
 
     def import_core(self, seg, k: int, data, rks, bl: int, br: int):
         dev = self.torch.device("cuda", self.torch.cuda.current_device())
         data = data.to(dev).contiguous()
         rks = rks.to(dev).contiguous()
-        self.torch.cuda.synchronize()
+        self.lib_stream.wait_stream(self.torch.cuda.current_stream())        # the received / copied tensors are ready before the import reads them
         self._lib.check(self._lib.lib().ttn_tt_core_import(seg.h, k + 1, data.data_ptr(), rks.data_ptr(), int(bl), int(br)))
-        self.D.sync()                              # `data` may be freed by the caller right after
+        self._keep.append((data, rks))             # alive until the library stream has consumed them (release())
+
+    def release(self):
+        """Host sync point at the end of a sharded op: the tensors handed to the library may be freed afterwards."""
+        self.D.sync()
+        self._keep = []
 
     def download(self, seg, b: int):
         """Cores of train b as numpy arrays (verification only)."""
@@ -108,39 +133,63 @@ class DeviceBackend:
     def ncores(self, seg) -> int:
         return seg.N
 
+    def batch(self, seg) -> int:
+        return seg.batch
+
+    def phys_dim(self, seg, k: int) -> int:
+        return int(seg.dims[k])
+
+    def core_capacity(self, seg, k: int) -> Tuple[int, int]:
+        """Rank capacities of core k's slot = the product ranks A.rks .* x.rks of that core."""
+        return int(seg.cap[k]), int(seg.cap[k + 1])
+
 
 # --------------------------------------------------------------------------------------------------------------------
 # transport
 # --------------------------------------------------------------------------------------------------------------------
 class DistTransport:
-    """Point-to-point hand-off of one boundary core (header, ranks, data) over torch.distributed."""
+    """Point-to-point hand-off of one boundary core over torch.distributed: ONE message per hand-off.
+
+    Sender and receiver agree on the message size without a header: the extents (BL, BR) of the core are upper bounds both
+    sides derive from what they hold — the rank capacities of the core's slot and max_bond (handoff_extents).  Message =
+    [batch x n*BL*BR doubles: every train's core, compact with its current ranks at the start of its row | batch x 2: the
+    two ranks, as float64 (exact below 2^53)]."""
 
     def __init__(self, dist, device="cpu"):
         import torch
         self.dist, self.torch, self.device = dist, torch, torch.device(device)
         self._pending = []                         # (request, tensor) of sends in flight: the tensors must stay alive
 
-    def send(self, payload, dst: int):
+    def send(self, payload, dst: int, n: int, BL: int, BR: int):
         """Non-blocking: the sender goes on with its next micro-batch while the neighbour is still busy."""
         data, rks, bl, br = payload
-        hdr = self.torch.tensor([data.shape[0], data.shape[1], bl, br], dtype=self.torch.int64, device=self.device)
-        for t in (hdr, rks.to(self.device).contiguous(), data.to(self.device).contiguous()):
-            self._pending.append((self.dist.isend(t, dst), t))
+        assert bl <= BL and br <= BR, (bl, br, BL, BR)
+        B, W = data.shape[0], n * BL * BR
+        msg = self.torch.zeros(B * (W + 2), dtype=self.torch.float64, device=data.device)
+        msg[: B * W].view(B, W)[:, : data.shape[1]] = data
+        msg[B * W:].view(B, 2).copy_(rks.to(self.torch.float64))
+        t = msg.to(self.device)
+        self._pending.append((self.dist.isend(t, dst), t))
 
     def flush(self):
         for req, _ in self._pending:
             req.wait()
         self._pending = []
 
-    def recv(self, src: int):
-        hdr = self.torch.empty(4, dtype=self.torch.int64, device=self.device)
-        self.dist.recv(hdr, src)
-        B, n, bl, br = (int(v) for v in hdr.tolist())
-        rks = self.torch.empty((B, 2), dtype=self.torch.int64, device=self.device)
-        data = self.torch.empty((B, n), dtype=self.torch.float64, device=self.device)
-        self.dist.recv(rks, src)
-        self.dist.recv(data, src)
-        return data, rks, bl, br
+    def recv(self, src: int, B: int, n: int, BL: int, BR: int):
+        W = n * BL * BR
+        msg = self.torch.empty(B * (W + 2), dtype=self.torch.float64, device=self.device)
+        self.dist.recv(msg, src)
+        return msg[: B * W].view(B, W), msg[B * W:].view(B, 2).to(self.torch.int64), BL, BR
+
+
+def handoff_extents(cap_left: int, cap_right: int, max_bond: int, direction: int) -> Tuple[int, int]:
+    """Upper bounds (BL, BR) of the ranks of a boundary core when it is handed over, from what BOTH neighbours know: the rank
+    capacities of its slot (the product ranks A.rks .* x.rks of the mirrored core) and max_bond.  L->R (direction 0): the left
+    bond has been truncated, the right one not yet; R->L (1): both have."""
+    bl = min(int(cap_left), int(max_bond))
+    br = min(int(cap_right), int(max_bond)) if direction else int(cap_right)
+    return bl, br
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -159,22 +208,24 @@ def sharded_apply_compress(backend, transport, rank: int, world: int, prepared: 
     micro-batches at the same time (pipeline, (world-1) stages of fill and drain per direction)."""
     segs = [backend.apply_prepared(p) for p in prepared]
     first, last = rank == 0, rank == world - 1
+    B, n0, nl = backend.batch(segs[0]), backend.phys_dim(segs[0], 0), backend.phys_dim(segs[0], n_ext - 1)
+    cap0, capl = backend.core_capacity(segs[0], 0), backend.core_capacity(segs[0], n_ext - 1)
     # ---- L -> R ----
     for seg in segs:
         if not first:
-            backend.import_core(seg, 0, *transport.recv(rank - 1))
-        if n_ext >= 2:
-            backend.sweep(seg, 0, n_ext - 2, max_bond, truncerr)
+            backend.import_core(seg, 0, *transport.recv(rank - 1, B, n0, *handoff_extents(*cap0, max_bond, 0)))
+        backend.lr_sweep(seg, n_ext, max_bond, truncerr, not first)
         if not last:
-            transport.send(backend.export_core(seg, n_ext - 1), rank + 1)
+            transport.send(backend.export_core(seg, n_ext - 1), rank + 1, nl, *handoff_extents(*capl, max_bond, 0))
     # ---- R -> L ----
     for seg in segs:
         if not last:
-            backend.import_core(seg, n_ext - 1, *transport.recv(rank + 1))
+            backend.import_core(seg, n_ext - 1, *transport.recv(rank + 1, B, nl, *handoff_extents(*capl, max_bond, 1)))
         if n_ext >= 2:
             backend.sweep(seg, n_ext - 2, 0, max_bond, truncerr)
         if not first:
-            transport.send(backend.export_core(seg, 0), rank - 1)
+            transport.send(backend.export_core(seg, 0), rank - 1, n0, *handoff_extents(*cap0, max_bond, 1))
     if transport is not None:
         transport.flush()
+    backend.release()
     return segs

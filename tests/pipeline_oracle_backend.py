@@ -30,7 +30,25 @@ class OracleBackend:
                 t = np.einsum("ijab,jcd->iacbd", a, x)              # (i, a', nu', a, nu): operator index fastest
                 y.append(np.asfortranarray(t.reshape(n, Rl * rl, Rr * rr, order="F")))
             out.append(y)
+        # rank capacities of every core's slot = the product ranks (what the device handle is created with)
+        self._cap = [(int(c.shape[1]), int(c.shape[2])) for c in out[0]]
         return out
+
+    def lr_sweep(self, seg, n_ext, max_bond, truncerr, first_real):
+        if n_ext >= 2:                              # (the product was formed by apply_prepared; an imported core 0 replaced its slot)
+            self.sweep(seg, 0, n_ext - 2, max_bond, truncerr)
+
+    def release(self):
+        pass
+
+    def batch(self, seg):
+        return len(seg)
+
+    def phys_dim(self, seg, k):
+        return int(seg[0][k].shape[0])
+
+    def core_capacity(self, seg, k):
+        return self._cap[k]
 
     def _train(self, cores):
         dims = tuple(int(c.shape[0]) for c in cores)
@@ -49,7 +67,7 @@ class OracleBackend:
         bl = max(int(c[k].shape[1]) for c in seg)
         br = max(int(c[k].shape[2]) for c in seg)
         n = int(seg[0][k].shape[0])
-        data = np.zeros((len(seg), n * bl * br))
+        data = np.zeros((len(seg), max(int(c[k].size) for c in seg)))
         rks = np.zeros((len(seg), 2), dtype=np.int64)
         for b, cores in enumerate(seg):
             c = cores[k]

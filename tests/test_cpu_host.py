@@ -48,7 +48,7 @@ def _ctypes_of(ctype: str):
         "int": [L.c_int], "int64_t": [L.c_int64], "double": [L.c_double],
         "int*": [L.POINTER(L.c_int), L.c_void_p], "int64_t*": [L.POINTER(L.c_int64), L.c_void_p],
         "double*": [L.POINTER(L.c_double), L.c_void_p], "float*": [L.POINTER(L.c_float)],
-        "double**": [L.POINTER(L.POINTER(L.c_double))],
+        "double**": [L.POINTER(L.POINTER(L.c_double))], "void**": [L.POINTER(L.c_void_p)],
         "ttn_tt_t": [L.c_void_p], "ttn_tto_t": [L.c_void_p], "ttn_tt_t*": [L.POINTER(L.c_void_p)], "ttn_tto_t*": [L.POINTER(L.c_void_p)],
     }
     return table[ctype]

@@ -111,11 +111,13 @@ def test_segment_bounds():
 
 
 @pytest.mark.gpu
-def test_core_sharded_compress_on_gpu_equals_single_process():
-    """Two ranks on one GPU (gloo transport): the sharded device result equals the unsharded device result."""
+@pytest.mark.parametrize("world,d,r,nmb,per_mb", [(2, 16, 16, 2, 3), (3, 13, 8, 2, 2), (2, 30, 64, 2, 2)])
+def test_core_sharded_compress_on_gpu_equals_single_process(world, d, r, nmb, per_mb):
+    """Ranks sharing one GPU (gloo transport, boundary cores staged through the host): the sharded device result — fused apply inside
+    every segment's L->R pass, one packed message per hand-off, event-ordered streams — equals the unsharded device result.  The last
+    case is BASELINE config C4's chain (d = 30, rank 64) cut in two."""
     import ttn_amd as T
     from ttn_amd import device as D
-    world, d, r, nmb, per_mb = 2, 16, 16, 2, 3
     glued = _run(world, True, d, r, nmb, per_mb, r)
     A = T.Delta(d)
     dA = T.DeviceTTO(A)
@@ -126,8 +128,7 @@ def test_core_sharded_compress_on_gpu_equals_single_process():
             g += 1
             dx = T.DeviceTT.from_host(x)
             dy = T.DeviceTT((2,) * d, [a * c for a, c in zip(A.tto_rks, x.ttv_rks)])
-            D.apply(dA, dx, dy)
-            D.tt_compress_(dy, r)
+            D.apply_compress(dA, dx, dy, r)
             y = dy.download(0)
             got = glued[m][b]
             assert [int(c.shape[2]) for c in got] == list(y.ttv_rks[1:])
