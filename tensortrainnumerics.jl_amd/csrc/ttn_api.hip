@@ -24,6 +24,7 @@ int ttn_wg512_init(void);
 size_t ttn_wg512_compress_args_bytes(void);
 int ttn_wg512_launch_compress(const void* args, size_t nbytes, int grid, hipStream_t stream);
 int ttn_wg512_selftest_eig(const double* G, double* Vst, int n, int r, int nev, double* sig, double* Xout, long long* clk, hipStream_t stream);
+int ttn_wg512_bench_gemm(int m, int n, int k, double* A, double* B, double* C, int ta, int tb, int reps, long long* cycles, int grid, hipStream_t stream);
 int ttn_wg512_selftest_gemm(int m, int n, int k, double* A, double* B, double* C, double alpha, double beta, int ta, int tb, hipStream_t stream);
 }
 
@@ -1536,16 +1537,23 @@ int ttn_bench_gemm(int64_t m, int64_t n, int64_t k, int ta, int tb, int64_t reps
     if (!cycles_out || m < 1 || n < 1 || k < 1 || reps < 1) return fail(TTN_ERR_ARG, "bad argument");
     double *dA = nullptr, *dB = nullptr, *dC = nullptr;
     long long* dcy = nullptr;
-    HIPCHK(hipMalloc((void**)&dA, sizeof(double) * m * k));
-    HIPCHK(hipMalloc((void**)&dB, sizeof(double) * k * n));
-    HIPCHK(hipMalloc((void**)&dC, sizeof(double) * m * n));
+    // TTN_BENCH_GRID workgroups at once, each on its own operands (default 1: one CU busy); TTN_WG512_SELFTEST: the 512-thread build
+    const int grid = getenv("TTN_BENCH_GRID") ? std::max(1, atoi(getenv("TTN_BENCH_GRID"))) : 1;
+    HIPCHK(hipMalloc((void**)&dA, sizeof(double) * m * k * grid));
+    HIPCHK(hipMalloc((void**)&dB, sizeof(double) * k * n * grid));
+    HIPCHK(hipMalloc((void**)&dC, sizeof(double) * m * n * grid));
     HIPCHK(hipMalloc((void**)&dcy, sizeof(long long)));
-    HIPCHK(hipMemsetAsync(dA, 0, sizeof(double) * m * k, g_stream));
-    HIPCHK(hipMemsetAsync(dB, 0, sizeof(double) * k * n, g_stream));
-    HIPCHK(hipMemsetAsync(dC, 0, sizeof(double) * m * n, g_stream));
-    hipLaunchKernelGGL(k_bench_gemm, dim3(1), dim3(TTN_WG), sizeof(double) * GEMM_LDS_TOTAL, g_stream, (int)m, (int)n, (int)k,
+    HIPCHK(hipMemsetAsync(dA, 0, sizeof(double) * m * k * grid, g_stream));
+    HIPCHK(hipMemsetAsync(dB, 0, sizeof(double) * k * n * grid, g_stream));
+    HIPCHK(hipMemsetAsync(dC, 0, sizeof(double) * m * n * grid, g_stream));
+    if (getenv("TTN_WG512_SELFTEST") && atoi(getenv("TTN_WG512_SELFTEST"))) {
+        const int rc512 = ttn_wg512_bench_gemm((int)m, (int)n, (int)k, dA, dB, dC, ta, tb, (int)reps, dcy, grid, g_stream);
+        if (rc512) return hipfail((hipError_t)rc512, "k_bench_gemm (512-thread build)");
+    } else {
+    hipLaunchKernelGGL(k_bench_gemm, dim3(grid), dim3(TTN_WG), sizeof(double) * GEMM_LDS_TOTAL, g_stream, (int)m, (int)n, (int)k,
                        dA, dB, dC, ta, tb, (int)reps, dcy);
     HIPCHK(hipGetLastError());
+    }
     long long cy = 0;
     HIPCHK(hipMemcpyAsync(&cy, dcy, sizeof(long long), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));

@@ -208,6 +208,56 @@ typedef __attribute__((address_space(3))) GemmDesc lds_gdesc;
 __device__ inline Idx ldsIdx(const __attribute__((address_space(3))) Idx* d) { return Idx{uni32(d->q), uni64(d->lo), uni64(d->hi)}; }
 __device__ inline View ldsView(const __attribute__((address_space(3))) View* v) { return View{(double*)uni64((long long)v->p), ldsIdx(&v->r), ldsIdx(&v->c)}; }
 
+// -------------------------------------------------------------------------------------------------
+// Element loops over global memory.  `for (e = tid; e < n; e += TTN_WG) dst[e] = f(src[e])` compiles to load, s_waitcnt vmcnt(0),
+// store per trip (no unrolling, possible aliasing): a full memory round trip per ELEMENT of a thread.  wg_batched runs such a loop
+// with U loads of a thread in flight before the first is used: load(e) returns what the element needs (index clamped: it must be
+// harmless to call it twice for an e < n), use(e, value) consumes it.  It is used inside OUT-OF-LINE leaf routines only: inlined
+// into the bond step the same loops cost 300 more spilled VGPRs (the step runs at the 128-register limit) and 19 % of its speed.
+// -------------------------------------------------------------------------------------------------
+template <int U, typename LoadF, typename UseF>
+__device__ __forceinline__ void wg_batched(long long n, LoadF load, UseF use) {
+    for (long long e0 = threadIdx.x; e0 < n; e0 += (long long)TTN_WG * U) {
+        decltype(load(0LL)) v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const long long e = e0 + (long long)u * TTN_WG; v[u] = load(e < n ? e : e0); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const long long e = e0 + (long long)u * TTN_WG; if (e < n) use(e, v[u]); }
+    }
+}
+// dst[e] = s * src[e], e < n
+__device__ __noinline__ void wg_copy_scale(double* dst, const double* src, long long n, double s_) {
+    dst = unip(dst); src = unip(src); n = uni64(n); s_ = unif64(s_);
+    wg_batched<8>(n, [&](long long e) { return src[e]; }, [&](long long e, double v) { dst[e] = v * s_; });
+}
+// max |src[e]|, e < n (all threads get it)
+__device__ __noinline__ double wg_absmax(const double* src, long long n, double* red) {
+    src = unip(src); n = uni64(n); red = unip(red);
+    double m_ = 0.0;
+    wg_batched<8>(n, [&](long long e) { return src[e]; }, [&](long long, double v) { m_ = fmax(m_, fabs(v)); });
+    return unif64(wg_max(m_, red));
+}
+// dst(i, j) = (lim_first ? i : j) < lim ? src[i + ld_first... : the commit copy of the factored route: element (row, col) of the rows x cols
+// matrix `src` (element stride rs between rows, cs between columns) goes to the View `dst`; entries whose column (col_lim) or row
+// (!col_lim) index is >= lim are written as zeros
+__device__ __noinline__ void wg_copy_to_view(View dst, const double* src, int rows, int cols, long long rs, long long cs, int lim, int col_lim) {
+    dst = uniView(dst); src = unip(src); rows = uni32(rows); cols = uni32(cols); rs = uni64(rs); cs = uni64(cs); lim = uni32(lim); col_lim = uni32(col_lim);
+    const bool row_fast = rs <= cs;
+    const int fast = row_fast ? rows : cols;                       // 32-bit index arithmetic (rows * cols < 2^31: at most 4096 x 16384)
+    wg_batched<8>((long long)rows * cols,
+                  [&](long long e) {
+                      const int ei = (int)e, lo = ei % fast, hi = ei / fast;
+                      const int i = row_fast ? lo : hi, j = row_fast ? hi : lo;
+                      return ((col_lim ? j : i) < lim) ? src[i * rs + j * cs] : 0.0;
+                  },
+                  [&](long long e, double v) {
+                      const int ei = (int)e, lo = ei % fast, hi = ei / fast;
+                      const int i = row_fast ? lo : hi, j = row_fast ? hi : lo;
+                      dst.p[ix(dst.r, i) + ix(dst.c, j)] = v;
+                  });
+}
+
+
 // max |C_ij| of the values a GEMM stored, for callers that rescale by it: saves a pass over C (wave max, then one LDS
 // atomic per wave; non-negative doubles order like their bit patterns)
 __device__ inline void gemm_publish_amax(const lds_gdesc* dsc, double cmax) {
@@ -440,28 +490,33 @@ __device__ TTN_NI_GEMMS void wg_gemm_small_impl(const GemmDesc* dsc_, double* ld
     // ---- stage all of A (m x k) and B (k x n), zero padding rows/cols up to the tile edge; 16 lanes walk the
     //      operand's fast (small-stride) index, the 64 lane groups its slow index: no divisions in the loops ----
     const int fx = tid & 15, sy = tid >> 4;
-    if (a_kfast) {
-        for (int r = sy; r < mp; r += TTN_WG / 16) {
-            const int ro = rowA[r];
-            for (int kk = fx; kk < k; kk += 16) As[kk * lda + r] = (r < m) ? Ag[ro + kA[kk]] : 0.0;
-        }
-    } else {
-        for (int kk = sy; kk < k; kk += TTN_WG / 16) {
-            const int ko = kA[kk];
-            for (int r = fx; r < mp; r += 16) As[kk * lda + r] = (r < m) ? Ag[rowA[r] + ko] : 0.0;
-        }
+    // The loads of a thread are issued in batches of GS_U before the first of them is awaited (written naively — load, wait, store
+    // per element — every element of a thread paid its own global-memory round trip: 16 of them in a row for a 64 x 64 x 128
+    // product, most of the time of these latency-bound GEMMs).  Out-of-range elements read element 0 and are zeroed.
+#define GS_U 8
+#define GEMM_SMALL_STAGE(DST, LDD, SRC, SLOWTAB, FASTTAB, NSLOW, NSLOW_VALID, NFAST, NFAST_VALID, SLOW_IS_K)                      \
+    for (int s_ = sy; s_ < (NSLOW); s_ += TTN_WG / 16) {                                                                        \
+        const int so_ = (s_ < (NSLOW_VALID)) ? SLOWTAB[s_] : 0;                                                                 \
+        for (int f0_ = fx; f0_ < (NFAST); f0_ += 16 * GS_U) {                                                                   \
+            double v_[GS_U];                                                                                                    \
+            _Pragma("unroll") for (int u_ = 0; u_ < GS_U; ++u_) {                                                               \
+                const int f_ = f0_ + 16 * u_;                                                                                   \
+                const bool ok_ = (s_ < (NSLOW_VALID)) && (f_ < (NFAST_VALID));                                                  \
+                v_[u_] = SRC[ok_ ? so_ + FASTTAB[f_] : 0];                                                                      \
+            }                                                                                                                   \
+            _Pragma("unroll") for (int u_ = 0; u_ < GS_U; ++u_) {                                                               \
+                const int f_ = f0_ + 16 * u_;                                                                                   \
+                const bool ok_ = (s_ < (NSLOW_VALID)) && (f_ < (NFAST_VALID));                                                  \
+                if (f_ < (NFAST)) DST[(SLOW_IS_K) ? s_ * (LDD) + f_ : f_ * (LDD) + s_] = ok_ ? v_[u_] : 0.0;                    \
+            }                                                                                                                   \
+        }                                                                                                                       \
     }
-    if (b_kfast) {
-        for (int c = sy; c < np; c += TTN_WG / 16) {
-            const int co = colB[c];
-            for (int kk = fx; kk < k; kk += 16) Bs[kk * ldb + c] = (c < n) ? Bg[co + kB[kk]] : 0.0;
-        }
-    } else {
-        for (int kk = sy; kk < k; kk += TTN_WG / 16) {
-            const int ko = kB[kk];
-            for (int c = fx; c < np; c += 16) Bs[kk * ldb + c] = (c < n) ? Bg[colB[c] + ko] : 0.0;
-        }
-    }
+    if (a_kfast) { GEMM_SMALL_STAGE(As, lda, Ag, rowA, kA, mp, m, k, k, 0) }          // slow = row, fast = k
+    else { GEMM_SMALL_STAGE(As, lda, Ag, kA, rowA, k, k, mp, m, 1) }                  // slow = k, fast = row
+    if (b_kfast) { GEMM_SMALL_STAGE(Bs, ldb, Bg, colB, kB, np, n, k, k, 0) }          // slow = column, fast = k
+    else { GEMM_SMALL_STAGE(Bs, ldb, Bg, kB, colB, k, k, np, n, 1) }                  // slow = k, fast = column
+#undef GEMM_SMALL_STAGE
+#undef GS_U
     __syncthreads();
     const int tm = mp >> 4, tn = np >> 4, ntile = tm * tn;
     const int k4 = k >> 2, krem = k & 3;
@@ -595,7 +650,7 @@ __device__ inline void lq_lds_whole(int p, int qc, const double* src, int lds_, 
     __syncthreads();
     gmem_f64* srcg = (gmem_f64*)src;                              // M2 is global memory: global_load / global_store, not FLAT
     gmem_wf64* dstg = (gmem_wf64*)dst;
-    for (int e = tid; e < p * qc; e += TTN_WG) A[e] = srcg[(long long)(e / qc) * lds_ + (e % qc)];
+    wg_batched<8>((long long)p * qc, [&](long long e) { return srcg[(e / qc) * lds_ + (e % qc)]; }, [&](long long e, double v) { A[e] = v; });
     __syncthreads();
     if (grp == 0) {                                               // reflector 0
         double s = 0.0;
@@ -1915,10 +1970,8 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
     if (SWAP == 0 && P.fast && rm < p && rm <= TTN_LDS_COLS && rm >= 2) {
         // scales
         double sa = 0.0, sb = 0.0;
-        for (long long e = tid; e < (long long)n1 * Dl * rm; e += TTN_WG) sa = fmax(sa, fabs(ck[e]));
-        for (long long e = tid; e < (long long)n2 * rm * Dr; e += TTN_WG) sb = fmax(sb, fabs(ck1[e]));
-        sa = unif64(wg_max(sa, S.red));
-        sb = unif64(wg_max(sb, S.red));
+        sa = wg_absmax(ck, (long long)n1 * Dl * rm, S.red);
+        sb = wg_absmax(ck1, (long long)n2 * rm * Dr, S.red);
         bool ok = (sa > 0.0) && (sb > 0.0);
         const double sA = wide ? sa : sb, sB = wide ? sb : sa;       // scale of A', B'
         const double s0 = sA * sB;
@@ -2066,14 +2119,8 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 const View Lo = wide ? Lfv : tview(Rfv);       // p x r
                 const View Ro = wide ? Rfv : tview(Lfv);       // r x q
                 __syncthreads();
-                for (long long e = tid; e < (long long)p * r; e += TTN_WG) {
-                    const int row = (int)(e % p), j = (int)(e / p);
-                    Lo.p[ix(Lo.r, row) + ix(Lo.c, j)] = (j < rk) ? LfT[(long long)j * p + row] : 0.0;
-                }
-                for (long long e = tid; e < (long long)r * q; e += TTN_WG) {
-                    const int j = (int)(e / q), col = (int)(e % q);
-                    Ro.p[ix(Ro.r, j) + ix(Ro.c, col)] = (j < rk) ? RfT[(long long)j * q + col] : 0.0;
-                }
+                wg_copy_to_view(Lo, LfT, p, r, 1, p, rk, 1);               // Lo[row, j] = LfT[row + p j], columns j >= rk zero
+                wg_copy_to_view(Ro, RfT, r, q, q, 1, rk, 0);               // Ro[j, col] = RfT[j q + col], rows j >= rk zero
                 if (tid == 0) *io.rank_out = r;
                 __syncthreads();
                 done = true;
@@ -2170,7 +2217,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             } else {
                 // =========================== route H: Householder LQ ===========================
                 if (need_lq) {
-                    for (long long e = tid; e < (long long)p * q; e += TTN_WG) S.M2[e] = S.M[e] * inv_s0;
+                    wg_copy_scale(S.M2, S.M, (long long)p * q, inv_s0);
                     __syncthreads();
                     wg_lq_blocked(p, q, S.M2, q, S.Vb, S.Wb, nullptr, nullptr, lds, S.Ts, S.Ss, S.taus, S.red);
                 }
@@ -2579,6 +2626,9 @@ __global__ void TTN_KERNEL_BOUNDS k_selftest_gemm(int m, int n, int k, double* A
 __global__ void TTN_KERNEL_BOUNDS k_bench_gemm(int m, int n, int k, double* A, double* B, double* C, int ta, int tb, int reps,
                                                       long long* cycles) {
     extern __shared__ double lds[];
+    // every workgroup of the grid works on its own copy of the operands (the buffers hold gridDim.x of them back to back): a grid
+    // of 2 x #CUs measures the GEMM with a second workgroup resident on the CU
+    A += (long long)blockIdx.x * m * k; B += (long long)blockIdx.x * k * n; C += (long long)blockIdx.x * m * n;
     const View Av = ta ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));
     const View Bv = tb ? mkview(B, plain(1), plain(k)) : mkview(B, plain(n), plain(1));
     __syncthreads();
@@ -2586,7 +2636,7 @@ __global__ void TTN_KERNEL_BOUNDS k_bench_gemm(int m, int n, int k, double* A, d
     for (int r = 0; r < reps; ++r) wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), 1.0, 0.0, lds);
     __syncthreads();
     const long long t1 = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0) *cycles = t1 - t0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = t1 - t0;
 }
 
 // LDS building-block micro-benchmark (ttn_bench_lds): G = I*n + smooth symmetric perturbation, then Cholesky or Jacobi.

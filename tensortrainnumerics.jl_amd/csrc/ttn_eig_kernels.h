@@ -488,7 +488,7 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
     for (int khi = N - 2; khi > 0; khi -= VROWS) {
     const int klo = (khi > VROWS) ? khi - VROWS : 0;
     __syncthreads();
-    for (int e_ = tid; e_ < (khi - klo) * 128; e_ += TTN_WG) L[e_] = Vst[klo * 128 + e_];
+    wg_batched<8>((long long)(khi - klo) * 128, [&](long long e_) { return Vst[klo * 128 + e_]; }, [&](long long e_, double v) { L[e_] = v; });
     __syncthreads();
     if (wave < 8) {
         typedef double __attribute__((ext_vector_type(2))) d2;

@@ -53,4 +53,11 @@ int ttn_wg512_selftest_gemm(int m, int n, int k, double* A, double* B, double* C
     return (int)hipGetLastError();
 }
 
+int ttn_wg512_bench_gemm(int m, int n, int k, double* A, double* B, double* C, int ta, int tb, int reps, long long* cycles, int grid, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(ttn_wg512::k_bench_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)COMPRESS_LDS_BYTES); attr = true; }
+    hipLaunchKernelGGL(ttn_wg512::k_bench_gemm, dim3(grid), dim3(TTN_WG), COMPRESS_LDS_BYTES, stream, m, n, k, A, B, C, ta, tb, reps, cycles);
+    return (int)hipGetLastError();
+}
+
 }  // extern "C"

@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ttn_amd as T
 T.ensure_init(0)
 L = T._lib.lib()
+print("build:", "512-thread" if os.environ.get("TTN_WG512_SELFTEST") else "1024-thread", " grid:", os.environ.get("TTN_BENCH_GRID", "1"))
 shapes = [  # (m, n, k, ta, tb, what)
+    (64, 64, 128, 0, 1, "F: B' B'^T"), (128, 64, 64, 0, 0, "F: Lf = A' T1"), (64, 128, 64, 1, 0, "F: Rf = T2^T B'"), (64, 64, 384, 0, 1, "G: check Ro Ro^T"),
     (128, 384, 192, 0, 0, "merge L->R"), (128, 128, 384, 0, 1, "gram M M^T"), (64, 384, 128, 1, 0, "split Vt = U^T M"),
     (128, 128, 64, 0, 0, "merge R->L"), (64, 64, 128, 1, 0, "gram A^T A (F)"), (64, 64, 64, 0, 0, "small 64^3"),
     (128, 128, 128, 0, 0, "128^3"), (128, 64, 128, 0, 0, "U = X W"), (192, 192, 128, 0, 0, "dot-like"),
