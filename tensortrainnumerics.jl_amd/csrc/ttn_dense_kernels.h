@@ -1816,6 +1816,142 @@ __device__ void wg_materialize_core(const CompressArgs& P, int b, int k) {
 // 2*p*Rl*rho_l*n2*rho_r flops instead of 2*p*(Rl*rho_l)*(n2*Rr*rho_r) — Rr times fewer — and the core never exists in HBM.
 // T lives in `Tbuf` (>= Rl*p*n2*rho_r doubles).  max|M| goes to *amax_lds.  Returns false (nothing done) if the shapes
 // do not qualify; the caller then materialises the core.
+// ---- the same merge in ONE pass, with the operator contraction in the GEMM epilogue (n2 = 2, small operator ranks) -----------------
+// The first version (wg_fused_merge below, still the general path) runs Rl separate GEMMs into a buffer T (Rl p n2 rho_r doubles,
+// 393 KB for the benchmark's steps), and a second pass reads T back, contracts with the operator core and writes M: measured inside
+// the kernel (TTN_PROF, 512-thread build, two workgroups per CU) 349 k clk for the three GEMMs — 14 % of the matrix pipe each: K = 64
+// is all prologue — plus 191 k clk for the contraction pass, per bond step.  Here a wave keeps the Rl accumulators T_a'[16 rows,
+// 16 (j, nu) columns] of its tiles in registers: they share every B fragment (x is read once, not Rl times), and when the K loop is
+// done the lane that holds column (j, nu) forms its share sum_a' T_a' A[s, j, a', a] of the n2 Rr outputs of that (row, nu), adds its
+// neighbour's (the other j: one DPP quad permutation) and writes M.  T never exists.
+// Layout: chunks of FM_BK = 8 values of nu' through two LDS stages (As[(a' FM_BK + kk) LDA + row], Bs[kk LDB + col]); a wave owns
+// one 16-row tile and two 16-column tiles ((j, nu) columns: 8 nu each) of a pass over CP = 32 * (waves / row tiles) columns.
+#define FM_BK 8
+__device__ __noinline__ bool wg_fused_merge_mfma(double* ck, const double* xc, const double* ac, double* M, int p, int q, int n1, int Dl,
+                                                 int rhl, int rhr, int Rl, int Rr, double* lds, double* amax_lds, double* red) {
+    ck = unip(ck); xc = unip(xc); ac = unip(ac); M = unip(M); lds = unip(lds); amax_lds = unip(amax_lds); red = unip(red);
+    p = uni32(p); q = uni32(q); n1 = uni32(n1); Dl = uni32(Dl); rhl = uni32(rhl); rhr = uni32(rhr); Rl = uni32(Rl); Rr = uni32(Rr);
+    constexpr int n2 = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int RT = p >> 4;                                           // row tiles
+    const int WR = RT < 8 ? RT : 8;                                  // waves along the rows (the A stage holds 128 rows: LDA = 145)
+    const int WC = TTN_NWAVES / WR;                                  // wave columns (>= 1)
+    const int CP = 32 * WC;                                          // (j, nu) columns per pass
+    const int ncol = n2 * rhr, nin = Rl * n2, nout = n2 * Rr;
+    constexpr int LDA = GEMM_LD;
+    const int LDB = (CP <= 32) ? 49 : (CP <= 64) ? 81 : GEMM_LD;     // all == 17 mod 32
+    const int stage = Rl * FM_BK * LDA + FM_BK * LDB;
+    if (Rl < 1 || Rl > 3 || Rr > 4 || (p & 15) || (rhl % FM_BK) || (ncol % CP) || (RT % WR) || WR * WC != TTN_NWAVES || CP > 128 ||
+        Rl * FM_BK * 16 * WR > 6 * TTN_WG || FM_BK * CP > 2 * TTN_WG || 2 * stage + 64 > GEMM_LDS_DOUBLES)
+        return false;
+    lds_f64* opl = (lds_f64*)lds + 2 * stage;                        // operator core: opl[o * nin + i], o = s + n2 a, i = j + n2 a'
+    __syncthreads();
+    for (int e = tid; e < nin * nout; e += TTN_WG) {
+        const int i = e % nin, o = e / nin;
+        opl[e] = ac[(o % n2) + n2 * ((i % n2) + n2 * ((i / n2) + (long long)Rl * (o / n2)))];
+    }
+    const long long ldk = (long long)n1 * Dl;                        // column stride of C_k as a (n1 Dl) x (Rl rho_l) matrix
+    const int wr = wave % WR, wc = wave / WR;
+    const int nchunk = rhl / FM_BK;
+    gmem_f64* Cg = (gmem_f64*)ck;
+    gmem_f64* Xg = (gmem_f64*)xc;
+    gmem_wf64* Mg = (gmem_wf64*)M;
+    double cmax = 0.0;
+    // staging assignment: A chunk = Rl * FM_BK * (16 WR) elements, row fastest; B chunk = FM_BK * CP elements, column fastest
+    const int arows = 16 * WR;
+    const int na_el = Rl * FM_BK * arows, nb_el = FM_BK * CP;
+    constexpr int NUA = 6, NUB = 2;                                  // elements per thread and chunk (enough for 3 * 8 * 128 / 512 and 8 * 128 / 512)
+    for (int rb = 0; rb < RT; rb += WR) {                            // row blocks of 16 WR rows
+        for (int c0 = 0; c0 < ncol; c0 += CP) {                      // column passes
+            mfma_acc_t acc[3][2];
+#pragma unroll
+            for (int a1 = 0; a1 < 3; ++a1) { acc[a1][0] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0}; acc[a1][1] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0}; }
+            int aoff[NUA], alds[NUA], boff[NUB], blds[NUB];
+            bool aok[NUA], bok[NUB];
+#pragma unroll
+            for (int u = 0; u < NUA; ++u) {
+                const int e = tid + TTN_WG * u;
+                aok[u] = e < na_el;
+                const int r = e % arows, rest = e / arows, kk = rest % FM_BK, a1 = rest / FM_BK;
+                const int row = 16 * rb + r;
+                // C_k[(al, s1), ga] at s1 + n1 (al + Dl ga), row = al + Dl s1, ga = a1 + Rl nu'
+                aoff[u] = aok[u] ? (row % Dl) * n1 + row / Dl + (int)(ldk * (a1 + (long long)Rl * kk)) : 0;
+                alds[u] = (a1 * FM_BK + kk) * LDA + r;
+            }
+#pragma unroll
+            for (int u = 0; u < NUB; ++u) {
+                const int e = tid + TTN_WG * u;
+                bok[u] = e < nb_el;
+                const int c = e % CP, kk = e / CP, col = c0 + c;
+                // x[j, nu', nu] at j + n2 (nu' + rho_l nu), col = j + n2 nu
+                boff[u] = bok[u] ? (col & 1) + n2 * (kk + rhl * (col >> 1)) : 0;
+                blds[u] = kk * LDB + c;
+            }
+            const int astep = (int)(ldk * Rl * FM_BK), bstep = n2 * FM_BK;       // address advance per chunk
+            double av[NUA], bv[NUB];
+#define FM_LOAD(CH)                                                                                                     \
+            { _Pragma("unroll") for (int u = 0; u < NUA; ++u) av[u] = Cg[aoff[u] + (CH) * astep];                       \
+              _Pragma("unroll") for (int u = 0; u < NUB; ++u) bv[u] = Xg[boff[u] + (CH) * bstep]; }
+#define FM_STORE(STG)                                                                                                   \
+            { lds_f64* As_ = (lds_f64*)lds + (STG) * stage; lds_f64* Bs_ = As_ + Rl * FM_BK * LDA;                      \
+              _Pragma("unroll") for (int u = 0; u < NUA; ++u) if (aok[u]) As_[alds[u]] = av[u];                         \
+              _Pragma("unroll") for (int u = 0; u < NUB; ++u) if (bok[u]) Bs_[blds[u]] = bv[u]; }
+            __syncthreads();                                         // the previous pass has consumed both stages (and opl is written)
+            FM_LOAD(0)
+            FM_STORE(0)
+            if (nchunk > 1) FM_LOAD(1)
+            __syncthreads();
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const lds_f64* As = (lds_f64*)lds + (ch & 1) * stage;
+                const lds_f64* Bs = As + Rl * FM_BK * LDA;
+#pragma unroll
+                for (int t = 0; t < FM_BK / 4; ++t) {
+                    const int kr = 4 * t + lk;
+                    const double b0 = Bs[kr * LDB + wc * 32 + li], b1 = Bs[kr * LDB + wc * 32 + 16 + li];
+#pragma unroll
+                    for (int a1 = 0; a1 < 3; ++a1) {
+                        if (a1 < Rl) {
+                            const double a = As[(a1 * FM_BK + kr) * LDA + wr * 16 + li];
+                            acc[a1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[a1][0], 0, 0, 0);
+                            acc[a1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[a1][1], 0, 0, 0);
+                        }
+                    }
+                    if (t == 0 && ch + 1 < nchunk) FM_STORE((ch + 1) & 1)
+                }
+                if (ch + 2 < nchunk) FM_LOAD(ch + 2)
+                __syncthreads();
+            }
+#undef FM_LOAD
+#undef FM_STORE
+            // ---- epilogue: lane (li, lk) holds T_a'[row = lk + 4 reg][column li] of its two column tiles; column = j + n2 nu ----
+            const int jl = li & 1;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int nu = (c0 + wc * 32 + ct * 16 + li) >> 1;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 16 * (rb + wr) + lk + 4 * reg;
+                    gmem_wf64* mrow = Mg + ((long long)row * q + (long long)nout * nu);
+                    for (int o = 0; o < nout; ++o) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int a1 = 0; a1 < 3; ++a1)
+                            if (a1 < Rl) v = fma(acc[a1][ct][reg], opl[o * nin + jl + n2 * a1], v);
+                        v += dpp_mov_f64<0xB1>(v);                   // + the other j (quad_perm [1,0,3,2]): both lanes of the pair hold the sum
+                        if ((o & 1) == jl) mrow[o] = v;              // the pair shares the stores
+                        cmax = fmax(cmax, fabs(v));
+                    }
+                }
+            }
+        }
+    }
+    cmax = wg_max(cmax, red);
+    if (tid == 0) *amax_lds = cmax;
+    __syncthreads();
+    return true;
+}
+
 #define FUSE_MAX_TERMS 16
 __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q, const View& Am, double* M, double* Tbuf,
                                long long tbuf_doubles, double* lds, double* amax_lds, double* red) {
@@ -1832,6 +1968,7 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
     double* ck = T.data + (long long)b * T.stride + T.off[k];
     double* xc = P.x.data + (long long)b * P.x.stride + P.x.off[k + 1];
     const double* ac = P.op.data + P.op.off[k + 1];
+    if (n2 == 2 && !(P.fast & 128) && wg_fused_merge_mfma(ck, xc, ac, M, p, q, n1, Dl, rhl, rhr, Rl, Rr, lds, amax_lds, red)) return true;
     const long long ldk = (long long)n1 * Dl;                           // column stride of C_k viewed as (n1*Dl) x r_mid
     for (int a1 = 0; a1 < Rl; ++a1) {
         const View Av = mkview(ck + a1 * ldk, Am.r, plain((long long)Rl * ldk));

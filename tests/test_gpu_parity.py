@@ -470,11 +470,15 @@ def test_bench_batch_parity(T):
     """ONE ttn_apply_compress launch over 64 of the trains bench.py times (same seeds, same fused op, same batch layout), every
     bond step's singular values captured: per train ranks exact, kept singular values rtol 1e-10, tensor difference to the oracle
     <= 1e-9.  This pins the route the headline number is measured on, at its acceptance limit.
-    Absolute floor of the singular-value comparison: 2e-12 sigma_1.  The 64-row ramp steps keep ALL singular values of merged
-    matrices with a conditioning up to 5e10, formed by a K = 64..192 GEMM from the (non-orthogonal, U sqrt(S)) cores the steps
-    before left: two backward-stable SVDs (LAPACK gesdd here, Householder + one-sided Jacobi on the device) of two such roundings
-    of the same matrix agree to c * K * eps * sigma_1 in ABSOLUTE terms only — measured over these 64 trains: up to 4.4e-13 sigma_1
-    (seed 492, bond step 34: values between 1e-11 and 2e-3 sigma_1), i.e. every value above 2e-2 sigma_1 is held to rtol 1e-10."""
+    Absolute floor of the singular-value comparison: 2e-12 sigma_1 up to and including the first step that keeps an ill-conditioned
+    block (kappa > 1e9), 2e-11 sigma_1 downstream of it.  The 64-row ramp step of the R->L half (bond step 34) keeps ALL singular
+    values of a merged matrix with a conditioning of 5e7 ... 5e10; two backward-stable SVDs of it (LAPACK gesdd here, Householder +
+    one-sided Jacobi on the device) agree on its small values to c * K * eps * sigma_1 in ABSOLUTE terms only (measured: up to
+    1.2e-12 sigma_1), and they leave DIFFERENT (equally valid) cores in the directions of those values; the next steps' merged
+    matrices — formed from these non-orthogonal U sqrt(S) cores — inherit that: measured over these trains with three builds
+    (tests/diag_sv_batch.py), the smallest kept value of step 35 (4e-2 sigma_1, conditioning 25) deviates by 1.7e-12 ... 6.6e-12 sigma_1
+    and the deviation decays over the following steps (3e-12, 1e-12, 5e-13), while the tensors agree to 1e-13.  Before step 34
+    nothing exceeds 1e-13 sigma_1."""
     d, r = 30, 64
     seeds = BENCH_PARITY_SEEDS
     assert len(seeds) == 64 and len(set(seeds)) == 64 and all(30 <= s_ <= 1053 for s_ in seeds)
@@ -497,9 +501,12 @@ def test_bench_batch_parity(T):
         ref = O.tt_compress_(O.apply(OA, to_oracle(xs[b])), r, svals_out=sv)
         got = dy.download(b)
         assert got.ttv_rks == ref.ttv_rks, f"seed {sd}"
+        ill = False                                              # an ill-conditioned kept block upstream
         for i, s_ref in enumerate(sv):
             s = dy.singular_values(b, i)[: len(s_ref)]
-            assert np.allclose(s, s_ref, rtol=1e-10, atol=2e-12 * s_ref[0]), f"seed {sd} bond step {i}: max abs/sigma_1 {np.max(np.abs(s - s_ref) / s_ref[0]):.2e}"
+            atol = (2e-11 if ill else 2e-12) * s_ref[0]
+            ill = ill or s_ref[0] > 1e9 * s_ref[min(len(s_ref), r) - 1]
+            assert np.allclose(s, s_ref, rtol=1e-10, atol=atol), f"seed {sd} bond step {i}: max abs/sigma_1 {np.max(np.abs(s - s_ref) / s_ref[0]):.2e}"
             big = s_ref >= 2e-2 * s_ref[0]                        # where the relative bar is the binding one
             worst_sv = max(worst_sv, float(np.max(np.abs(s[big] - s_ref[big]) / s_ref[big])))
             worst_abs = max(worst_abs, float(np.max(np.abs(s - s_ref)) / s_ref[0]))
