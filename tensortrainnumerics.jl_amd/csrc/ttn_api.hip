@@ -516,7 +516,13 @@ int ttn_apply(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y) {
     for (int m = 0; m <= d; ++m) if (y->cap[m] < A->rks[m] * x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_apply: destination capacity too small");
     for (int k = 0; k < d; ++k) maxfib = std::max<long long>(maxfib, (long long)x->bound[k] * x->bound[k + 1]);
     hipLaunchKernelGGL(k_ranks_mul_op, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), A->dev(), x->dev());
-    hipLaunchKernelGGL(k_apply, stream_grid(maxfib, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, A->dev(), x->dev(), y->dev());
+    // LDS of k_apply: the largest operator core (if it fits TTN_APPLY_LDS_DOUBLES) + the store-transpose buffer for the largest left rank
+    long long amax_ = 0, rlmax_ = 1;
+    for (int k = 0; k < d; ++k) { amax_ = std::max<long long>(amax_, (long long)A->dims[k] * A->dims[k] * A->rks[k] * A->rks[k + 1]); rlmax_ = std::max<long long>(rlmax_, A->rks[k]); }
+    const int lds_a = amax_ <= TTN_APPLY_LDS_DOUBLES ? (int)amax_ : 0;
+    const int lds_rl = rlmax_ <= TTN_APPLY_MAX_RL ? (int)rlmax_ : 0;
+    const size_t apply_lds = sizeof(double) * (size_t)((lds_a + 1) & ~1) + sizeof(double) * 2 * (size_t)(TTN_STREAM_TB / 64) * lds_rl * 64;
+    hipLaunchKernelGGL(k_apply, stream_grid(maxfib, d, x->batch), dim3(TTN_STREAM_TB), apply_lds, g_stream, A->dev(), x->dev(), y->dev(), lds_a, lds_rl);
     HIPCHK(hipGetLastError());
     for (int m = 0; m <= d; ++m) y->bound[m] = A->rks[m] * x->bound[m];
     std::fill(y->ot.begin(), y->ot.end(), 0);     // zeros_tt (tt_operations.jl:103)
@@ -604,7 +610,7 @@ int ttn_scale(double a, ttn_tt_t x, ttn_tt_t y) {
     long long maxsz = 0;
     for (int k = 0; k < d; ++k) maxsz = std::max<long long>(maxsz, (long long)x->dims[k] * x->bound[k] * x->bound[k + 1]);
     if (x != y) hipLaunchKernelGGL(k_ranks_copy, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), x->dev());
-    hipLaunchKernelGGL(k_scale, stream_grid(maxsz, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), a, which, a == 0.0 ? 1 : 0, which_b);
+    hipLaunchKernelGGL(k_scale, stream_grid((maxsz + 7) / 8, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), a, which, a == 0.0 ? 1 : 0, which_b);
     HIPCHK(hipGetLastError());
     y->bound = x->bound;
     if (a == 0.0) std::fill(y->ot.begin(), y->ot.end(), 0); else y->ot = x->ot;
@@ -627,7 +633,7 @@ int ttn_scale_batch(const double* a, ttn_tt_t x, ttn_tt_t y) {
     long long maxsz = 0;
     for (int k = 0; k < d; ++k) maxsz = std::max<long long>(maxsz, (long long)x->dims[k] * x->bound[k] * x->bound[k + 1]);
     if (x != y) hipLaunchKernelGGL(k_ranks_copy, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), x->dev());
-    hipLaunchKernelGGL(k_scale_batch, stream_grid(maxsz, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), (const double*)g_dout, which, which_b);
+    hipLaunchKernelGGL(k_scale_batch, stream_grid((maxsz + 7) / 8, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), (const double*)g_dout, which, which_b);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g_stream));      // `a` is caller memory and g_dout is reused by ttn_dot
     y->bound = x->bound;

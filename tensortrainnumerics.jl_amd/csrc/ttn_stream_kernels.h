@@ -45,8 +45,12 @@ __global__ void k_ranks_copy(TTDev y, TTDev x) {
 // Y_k[:, a' + Rl*v', a + Rr*v].  For a fixed a the Rl fibres a' = 0..Rl-1 are contiguous (n*Rl doubles, 48 B for the
 // Laplacian) and consecutive threads (consecutive v') continue the same run, so a wave writes Rr contiguous
 // runs of 64*n*Rl doubles: fully coalesced stores, one integer division per thread, 16 B read per 144 B written.
-__global__ void __launch_bounds__(TTN_STREAM_TB) k_apply(TTODev A, TTDev x, TTDev y) {
-    __shared__ double As[TTN_APPLY_LDS_DOUBLES];
+// Dynamic LDS, sized by the host for the operator at hand (lds_a doubles for the operator core, then lds_rl * 64 double2 per wave for
+// the store transpose): with the maximum sizes allocated statically (64 KB per 256-thread block) only two blocks fitted a CU —
+// 8 waves, far too few to keep 3 GB of streaming stores in flight.
+__global__ void __launch_bounds__(TTN_STREAM_TB) k_apply(TTODev A, TTDev x, TTDev y, int lds_a, int lds_rl) {
+    extern __shared__ double apply_smem[];
+    double* As = apply_smem;
     const int k = blockIdx.y, b = blockIdx.z;
     const int n = x.dims[k];
     const int Rl = (int)A.rks[k], Rr = (int)A.rks[k + 1];
@@ -57,7 +61,7 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_apply(TTODev A, TTDev x, TTDe
     if (first >= total) return;
     const double* Ak = A.data + A.off[k];
     const int asz = n * n * Rl * Rr;
-    const bool in_lds = asz <= TTN_APPLY_LDS_DOUBLES;
+    const bool in_lds = asz <= lds_a;
     if (in_lds) {
         for (int e = threadIdx.x; e < asz; e += blockDim.x) As[e] = Ak[e];
         __syncthreads();
@@ -71,13 +75,13 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_apply(TTODev A, TTDev x, TTDe
     // right index, so for every operator right index `ar` its Rl*64 output fibres are one contiguous run of Rl*64*16 bytes.
     // Per-lane stores would hit that run 16 bytes at a stride of Rl*16 (Rl partial passes over every cache line); instead the
     // wave transposes the run through LDS and writes it with fully coalesced 16-byte-per-lane stores.
-    __shared__ double2 Tr[TTN_STREAM_TB / 64][TTN_APPLY_MAX_RL * 64];
-    if (n == 2 && (rl & 63) == 0 && Rl <= TTN_APPLY_MAX_RL && (total % blockDim.x) == 0) {
+    double2* Tr = reinterpret_cast<double2*>(apply_smem + ((lds_a + 1) & ~1));
+    if (n == 2 && (rl & 63) == 0 && Rl <= lds_rl && (total % blockDim.x) == 0) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        double2* tr = Tr[wv];
-        for (long long e = first + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-            const int vl = (int)(e % rl), vr = (int)(e / rl);
-            const double2 xv = *reinterpret_cast<const double2*>(Xk + 2 * e);
+        double2* tr = Tr + (long long)wv * lds_rl * 64;
+        for (unsigned int e = (unsigned int)first + threadIdx.x; e < (unsigned int)total; e += gridDim.x * blockDim.x) {       // (32-bit index arithmetic)
+            const int vl = (int)(e % (unsigned int)rl), vr = (int)(e / (unsigned int)rl);
+            const double2 xv = *reinterpret_cast<const double2*>(Xk + 2 * (long long)e);
             const int vl0 = vl - lane;                                  // first left index of this wave (uniform)
             for (int ar = 0; ar < Rr; ++ar) {
                 const double* ap = Ap + 4 * (long long)Rl * ar;
@@ -92,9 +96,11 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_apply(TTODev A, TTDev x, TTDe
                 for (int t = 0; t < Rl; ++t) {
                     const double2 o = tr[64 * t + lane];
                     // non-temporal: y is written once and read by a later kernel; measured on C3, B = 256: 0.85 ms (3.8 TB/s)
-                    // against 1.03 ms with plain stores and 0.95 ms for the per-lane strided stores below
-                    __builtin_nontemporal_store(o.x, &yo[64 * t + lane].x);
-                    __builtin_nontemporal_store(o.y, &yo[64 * t + lane].y);
+                    // against 1.03 ms with plain stores and 0.95 ms for the per-lane strided stores below.  ONE 16-byte store per
+                    // lane (a native 2-vector: the builtin on the two members of a double2 emits two 8-byte stores)
+                    typedef double d2v_t __attribute__((ext_vector_type(2)));
+                    d2v_t ov; ov.x = o.x; ov.y = o.y;
+                    __builtin_nontemporal_store(ov, reinterpret_cast<d2v_t*>(&yo[64 * t + lane]));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -102,8 +108,8 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_apply(TTODev A, TTDev x, TTDe
         return;
     }
 #endif
-    for (long long e = first + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int vl = (int)(e % rl), vr = (int)(e / rl);
+    for (unsigned int e = (unsigned int)first + threadIdx.x; e < (unsigned int)total; e += gridDim.x * blockDim.x) {
+        const int vl = (int)(e % (unsigned int)rl), vr = (int)(e / (unsigned int)rl);
         const double* xs = Xk + (long long)n * e;
         if (n == 2) {
             const double x0 = xs[0], x1 = xs[1];
@@ -147,9 +153,12 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_hadamard(TTDev x, TTDev y, TT
     const double* Xk = x.data + (long long)b * x.stride + x.off[k];
     const double* Yk = y.data + (long long)b * y.stride + y.off[k];
     double* Zk = z.data + (long long)b * z.stride + z.off[k];
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int p = (int)(e % P), q = (int)(e / P);
-        const int ay = p % ryl, ax = p / ryl, by = q % ryr, bx = q / ryr;
+    // 32-bit index arithmetic (a core has fewer than 2^31 fibres: the host refuses larger ones): the 64-bit divisions of the first
+    // version were most of the kernel's instructions, and the kernel was bound by them, not by HBM
+    const unsigned int utotal = (unsigned int)total, uP = (unsigned int)P;
+    for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < utotal; e += gridDim.x * blockDim.x) {
+        const unsigned int p = e % uP, q = e / uP;
+        const unsigned int ay = p % (unsigned int)ryl, ax = p / (unsigned int)ryl, by = q % (unsigned int)ryr, bx = q / (unsigned int)ryr;
         const double* xs = Xk + (long long)n * (ax + (long long)rxl * bx);
         const double* ys = Yk + (long long)n * (ay + (long long)ryl * by);
         double* zo = Zk + (long long)n * e;
@@ -178,8 +187,9 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_add(TTDev x, TTDev y, TTDev z
     const double* Xk = x.data + (long long)b * x.stride + x.off[k];
     const double* Yk = y.data + (long long)b * y.stride + y.off[k];
     double* Zk = z.data + (long long)b * z.stride + z.off[k];
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int a = (int)(e % zl), c = (int)(e / zl);
+    const unsigned int utotal = (unsigned int)total;
+    for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < utotal; e += gridDim.x * blockDim.x) {
+        const int a = (int)(e % (unsigned int)zl), c = (int)(e / (unsigned int)zl);
         const double* src = nullptr;
         // row block: first core has the single row shared by X and Y; column block likewise at the end
         const bool ax = (k == 0) ? true : (a < rxl);
@@ -196,6 +206,10 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_add(TTDev x, TTDev y, TTDev z
             src = Yk + (long long)n * ((a - rxl) + (long long)ryl * (c - rxr));
         }
         double* zo = Zk + (long long)n * e;
+        if (n == 2) {
+            double2 o = src ? *reinterpret_cast<const double2*>(src) : double2{0.0, 0.0};
+            *reinterpret_cast<double2*>(zo) = o;
+        } else
         for (int s = 0; s < n; ++s) zo[s] = src ? src[s] : 0.0;
     }
 }
@@ -212,8 +226,16 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_scale(TTDev x, TTDev y, doubl
     const double* Xk = x.data + (long long)b * x.stride + x.off[k];
     double* Yk = y.data + (long long)b * y.stride + y.off[k];
     const double f = (k == which) ? a : 1.0;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
-        Yk[e] = zero ? 0.0 : ((k == which) ? f * Xk[e] : Xk[e]);
+    // 16 bytes per lane and trip (every slot is 16-byte aligned), a scalar tail for an odd count
+    const long long t2 = total >> 1;
+    const double2* X2 = reinterpret_cast<const double2*>(Xk);
+    double2* Y2 = reinterpret_cast<double2*>(Yk);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < t2; e += (long long)gridDim.x * blockDim.x) {
+        double2 v = zero ? double2{0.0, 0.0} : X2[e];
+        if (k == which && !zero) { v.x *= f; v.y *= f; }
+        Y2[e] = v;
+    }
+    if ((total & 1) && blockIdx.x == 0 && threadIdx.x == 0) Yk[total - 1] = zero ? 0.0 : ((k == which) ? f * Xk[total - 1] : Xk[total - 1]);
 }
 
 // per-train scalar: y_b = a[b] * x_b (a on the device); a[b] == 0 writes the zero train
@@ -225,8 +247,15 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_scale_batch(TTDev x, TTDev y,
     const double* Xk = x.data + (long long)b * x.stride + x.off[k];
     double* Yk = y.data + (long long)b * y.stride + y.off[k];
     const double f = a[b];
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
-        Yk[e] = (f == 0.0) ? 0.0 : ((k == which) ? f * Xk[e] : Xk[e]);
+    const long long t2 = total >> 1;
+    const double2* X2 = reinterpret_cast<const double2*>(Xk);
+    double2* Y2 = reinterpret_cast<double2*>(Yk);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < t2; e += (long long)gridDim.x * blockDim.x) {
+        double2 v = (f == 0.0) ? double2{0.0, 0.0} : X2[e];
+        if (k == which && f != 0.0) { v.x *= f; v.y *= f; }
+        Y2[e] = v;
+    }
+    if ((total & 1) && blockIdx.x == 0 && threadIdx.x == 0) Yk[total - 1] = (f == 0.0) ? 0.0 : ((k == which) ? f * Xk[total - 1] : Xk[total - 1]);
 }
 
 // replicate train src over the whole batch (cores + ranks)
