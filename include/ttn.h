@@ -89,9 +89,13 @@ int ttn_apply(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y);
  * `orthogonalize(psi; i=k)` (:769) is not computed: tt_compress! discards its value (:779,:785). */
 int ttn_compress(ttn_tt_t psi, int64_t max_bond, double truncerr, int64_t sweeps);
 
-/* status of the last ttn_compress / ttn_bond_truncate on this batch (synchronises): returns
- * TTN_ERR_NO_CONVERGENCE if the Jacobi SVD of any bond hit its sweep limit; if non-null,
- * total_jacobi_sweeps[b] receives the number of Jacobi sweeps train b used (diagnostics). */
+/* Device-side status of the handle (synchronises).  Every call that runs bond steps or local solves on psi — ttn_compress,
+ * ttn_apply_compress, ttn_bond_truncate, ttn_sweep, ttn_apply_sweep, ttn_swap_sites, ttn_hadamard_ttm, ttn_ttv_decomp, the linear
+ * solvers — records per train the FIRST condition its kernels meet: TTN_ERR_CAPACITY (a rank outgrew its slot),
+ * TTN_ERR_NO_CONVERGENCE (a Jacobi SVD / eigensolver hit its sweep limit), TTN_ERR_SINGULAR (singular local system).  The record is
+ * STICKY per handle: it survives later calls and is returned — and cleared — by this query, so a chain of asynchronous calls needs
+ * one query at its end.  If non-null, total_jacobi_sweeps[b] receives the number of Jacobi sweeps train b used in the last call
+ * (diagnostics). */
 int ttn_compress_status(ttn_tt_t psi, int64_t* total_jacobi_sweeps);
 
 /* Rank bounds of tt_compress! (k = 0) or one _tt_bond_truncate! (k = 1-based bond).  The reference keeps

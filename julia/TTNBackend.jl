@@ -8,7 +8,8 @@
 module TTNBackend
 
 using TensorTrainNumerics
-import TensorTrainNumerics: TTvector, TToperator, orthogonalize, tt_compress!, _tt_bond_truncate!, hadamard, add!, r_and_d_to_rks, zeros_tt
+import TensorTrainNumerics: TTvector, TToperator, orthogonalize, tt_compress!, _tt_bond_truncate!, hadamard, add!, r_and_d_to_rks, zeros_tt,
+    _applyH1_lsr, _applyH0, _update_left_env, _update_right_env, _applyH2_lsr
 import Base: *, +
 
 const LIB = get(ENV, "TTN_LIB", joinpath(@__DIR__, "..", "tensortrainnumerics.jl_amd", "libttn_hip.so"))
@@ -190,5 +191,53 @@ end
 #   ccall((:ttn_mals_linsolve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64), A, b, x0, x, tol, rmax)
 #   ccall((:ttn_dmrg_linsolve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Int64}),
 #         A, b, x0, x, tol, length(sweep_schedule), sweep_schedule, rmax_schedule)      # dmrg_linsolve(...; N = 2), dmrg.jl:388
+#   ccall((:ttn_dmrg_linsolve_it, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Int64}, Cint, Int64, Float64, Int64),
+#         A, b, x0, x, tol, length(sweep_schedule), sweep_schedule, rmax_schedule, it_solver, linsolv_maxiter, linsolv_tol, itslv_thresh)
+# (the keyword form, dmrg.jl:392-396: local systems above itslv_thresh unknowns — or all of them with it_solver — by matrix-free CG).
+#
+# Status is sticky per handle: ttn_compress_status(h, C_NULL) returns the first error any compress / sweep / swap / solver call
+# recorded on h since the last query (capacity -5, Jacobi sweep limit -9, singular local system -10) and clears it.
+
+# ---- TDVP local contractions (src/solvers/tdvp.jl:29-43, :205-208) ------------------------------------------------------------
+# The five @tensor kernels of tdvp1sweep! / tdvp2sweep!, for Float64 and ComplexF64 arrays in the layouts the sweeps hold
+# (sites (l,s,r), operator cores (a,s,b,s')).  KrylovKit's exponentiate keeps calling them as closures, unchanged.
+const _TE = Union{Float64, ComplexF64}
+_cplx(::Type{Float64}) = Cint(0)
+_cplx(::Type{ComplexF64}) = Cint(1)
+_f64ptr(X::Array{T}) where {T <: _TE} = Ptr{Float64}(pointer(X))
+
+function _tdvp_contract(op::Int, ::Type{T}, dims7::NTuple{7, Int}, FL, FR, X, M1, M2, out::Array{T}) where {T <: _TE}
+    d7 = Int64[dims7...]
+    p(Z) = Z === nothing ? Ptr{Float64}(C_NULL) : _f64ptr(Z)
+    GC.@preserve FL FR X M1 M2 out d7 _chk(ccall((:ttn_tdvp_contract_f64, LIB), Cint,
+        (Cint, Cint, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint),
+        op, _cplx(T), 1, d7, p(FL), p(FR), p(X), p(M1), p(M2), _f64ptr(out), 0))
+    return out
+end
+
+function _applyH1_lsr(AC::Array{T, 3}, FL::Array{T, 3}, FR::Array{T, 3}, M::Array{T, 4}) where {T <: _TE}
+    Dl, d, Dr = size(AC); a, b = size(M, 1), size(M, 3)
+    return _tdvp_contract(0, T, (Dl, d, Dr, a, b, 1, 1), FL, FR, AC, M, nothing, Array{T}(undef, Dl, d, Dr))
+end
+
+function _applyH0(C::Array{T, 2}, FL::Array{T, 3}, FR::Array{T, 3}) where {T <: _TE}
+    Dl, Dr = size(C); a = size(FL, 2)
+    return _tdvp_contract(1, T, (Dl, 1, Dr, a, 1, 1, 1), FL, FR, C, nothing, nothing, Array{T}(undef, Dl, Dr))
+end
+
+function _update_left_env(A::Array{T, 3}, M::Array{T, 4}, FL::Array{T, 3}) where {T <: _TE}
+    Dl, d, Dr = size(A); a_in, a_out = size(M, 1), size(M, 3)
+    return _tdvp_contract(2, T, (Dl, d, Dr, a_in, a_out, 1, 1), FL, nothing, A, M, nothing, Array{T}(undef, Dr, a_out, Dr))
+end
+
+function _update_right_env(A::Array{T, 3}, M::Array{T, 4}, FR::Array{T, 3}) where {T <: _TE}
+    Dl, d, Dr = size(A); a_out, a_in = size(M, 1), size(M, 3)
+    return _tdvp_contract(3, T, (Dl, d, Dr, a_in, a_out, 1, 1), nothing, FR, A, M, nothing, Array{T}(undef, Dl, a_out, Dl))
+end
+
+function _applyH2_lsr(AAC::Array{T, 4}, FL::Array{T, 3}, FR::Array{T, 3}, M1::Array{T, 4}, M2::Array{T, 4}) where {T <: _TE}
+    Dl, d1, d2, Dr = size(AAC); a, b, c = size(M1, 1), size(M1, 3), size(M2, 3)
+    return _tdvp_contract(4, T, (Dl, d1, Dr, a, b, c, d2), FL, FR, AAC, M1, M2, Array{T}(undef, Dl, d1, d2, Dr))
+end
 
 end # module
