@@ -749,6 +749,7 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     if (P.fused) { P.op = fuseA->dev(); P.x = fusex->dev(); }
     else { memset(&P.op, 0, sizeof(P.op)); memset(&P.x, 0, sizeof(P.x)); }
     P.prof = nullptr;
+    { const char* e = getenv("TTN_PROF_STEP"); P.prof_step = e ? atoi(e) : -1; }
     if (getenv("TTN_PROF")) {
         static long long* d_prof = nullptr; static int prof_cap = 0;
         if (prof_cap < psi->batch) { if (d_prof) hipFree(d_prof); HIPCHK(hipMalloc((void**)&d_prof, sizeof(long long) * 136 * psi->batch)); prof_cap = psi->batch; }
@@ -947,7 +948,7 @@ static int launch_chain(int kind, ttn_tt_t x, ttn_tt_t y, ttn_tt_t z, int n, int
     P.sv_out = nullptr; P.sv_steps = 0;
     P.status = z->d_status;                 // the handle the chain writes (kind 2: in place on z)
     P.sweep_stats = z->d_status + batch;
-    P.prof = nullptr;
+    P.prof = nullptr; P.prof_step = -1;
     { const char* e = getenv("TTN_JTOL"); P.jtol_mult = e ? atof(e) : 1.0; }
     { const char* e = getenv("TTN_JNEG"); P.jneg_mult = e ? atof(e) : 1.0; }
     P.fast = 0;

@@ -131,6 +131,7 @@ __device__ inline double wg_sum(double v, double* red) {
     if (l == 0) red[w] = v;
     __syncthreads();
     double t = (l < nw) ? red[l] : 0.0;
+    __syncthreads();                                   // red is free again: the caller's next routine may write it at once
     t = wave_sum(t);
     return t;
 }
@@ -141,6 +142,7 @@ __device__ inline double wg_max(double v, double* red) {
     if (l == 0) red[w] = v;
     __syncthreads();
     double t = (l < nw) ? red[l] : 0.0;
+    __syncthreads();                                   // (as above)
     t = wave_max(t);
     return t;
 }
@@ -600,6 +602,118 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
     } else {
         wg_gemm_impl<4>(dsc, lds);
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// wg_syrk: G = alpha * A A^T, A (p x q, p <= 128) and G (p x p, both triangles written) through Views in global memory.
+// The Gram products of a bond step (M M^T, the a-posteriori checks Rf Rf^T / Lf^T Lf, route F's A'^T A' and B' B'^T) are
+// 64..128 rows x a long K: as general GEMMs they ran the tiled form at 25 % of the matrix pipe (128 x 128 x 384: both operands staged
+// although they are the same matrix, a barrier per 16 k) or the chunked one-shot form (64 x 64 x 384: seven K chunks, each read-modify-
+// writing C in memory).  Here A is staged ONCE per K chunk (k-major, leading dimension == 17 mod 32 like the GEMM's) and serves both
+// fragment operands — frag(tb) = A[16 tb + lane&15][k + lane>>4] is the A fragment of tile row tb and the B fragment of tile column
+// tb alike —, only the tiles on and below the diagonal are computed (36 of 64 for p = 128) with the accumulators in registers over all
+// of K, and the global loads of chunk c + 1 are in flight (registers) while chunk c is multiplied.
+//   KC16 x 16 = k per chunk, JMAX = rows per thread of a chunk, MAXT = tiles per wave (all sized per build by the wrapper below).
+// -------------------------------------------------------------------------------------------------
+#define SYRK_QMAX (2 * GEMM_TAB_ENTRIES - 128)           // k offsets tabulated once (32-bit entries behind the descriptor)
+template <int KC16, int JMAX, int MAXT>
+__device__ TTN_NI_GEMM void wg_syrk_impl(const GemmDesc* dsc_, double* lds) {
+    const lds_gdesc* dsc = (const lds_gdesc*)dsc_;
+    constexpr int KC = 16 * KC16, RG = TTN_WG / 16;                 // k per chunk; row groups (16 lanes walk k)
+    const int p = uni32(dsc->m), q = uni32(dsc->k);
+    const View A = ldsView(&dsc->A), C = ldsView(&dsc->C);
+    const double alpha = unif64(dsc->alpha);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int pp = (p + 15) & ~15, LD = small_ld(p);
+    lds_f64* Cs = (lds_f64*)lds;                                    // Cs[kk * LD + row]
+    lds_i32* rowT = (lds_i32*)(lds + GEMM_LDS_DOUBLES + 32);       // 128 entries
+    lds_i32* colT = rowT + 128;                                     // q entries
+    gmem_f64* Ag = (gmem_f64*)A.p;
+    for (int i = tid; i < 128; i += TTN_WG) rowT[i] = (i < p) ? (int)ix(A.r, i) : 0;
+    for (int i = tid; i < q; i += TTN_WG) colT[i] = (int)ix(A.c, i);
+    // tiles of this wave: t = wave, wave + NWAVES, ... over the lower triangle, t = tr (tr + 1) / 2 + tc
+    const int nt = pp >> 4, ntile = nt * (nt + 1) / 2;
+    int t_r[MAXT], t_c[MAXT];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        const int t = wave + u * TTN_NWAVES;
+        int tr = 0, base = 0;
+        while (base + tr + 1 <= t) { base += tr + 1; ++tr; }
+        t_r[u] = uni32((t < ntile) ? tr : -1); t_c[u] = uni32(t - base);
+    }
+    mfma_acc_t acc[MAXT];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) acc[u] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+    const int fx = tid & 15, sy = tid >> 4;
+    double v[JMAX][KC16];
+    __syncthreads();
+#define SYRK_LOAD(K0)                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < JMAX; ++j) {                                                                   \
+        const int row = sy + RG * j;                                                                                    \
+        const int ro = (row < p) ? rowT[row] : 0;                                                                       \
+        _Pragma("unroll") for (int u = 0; u < KC16; ++u) {                                                               \
+            const int kk = (K0) + fx + 16 * u;                                                                          \
+            v[j][u] = Ag[(row < p && kk < q) ? ro + colT[kk] : 0];                                                      \
+        }                                                                                                               \
+    }
+    SYRK_LOAD(0)
+    for (int k0 = 0; k0 < q; k0 += KC) {
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int row = sy + RG * j;
+#pragma unroll
+            for (int u = 0; u < KC16; ++u) {
+                const int kl = fx + 16 * u;
+                if (row < pp) Cs[kl * LD + row] = (row < p && k0 + kl < q) ? v[j][u] : 0.0;
+            }
+        }
+        __syncthreads();
+        if (k0 + KC < q) { SYRK_LOAD(k0 + KC) }
+        const int ksteps = (q - k0 < KC) ? (q - k0 + 3) >> 2 : KC / 4;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const lds_f64* rowp = Cs + (4 * ks + lk) * LD + li;
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) {
+                if (t_r[u] >= 0) {                                   // wave-uniform
+                    const double a = rowp[16 * t_r[u]], b = rowp[16 * t_c[u]];
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef SYRK_LOAD
+    gmem_wf64* Cg = (gmem_wf64*)C.p;
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        if (t_r[u] < 0) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int gi = 16 * t_r[u] + lk + 4 * reg, gj = 16 * t_c[u] + li;
+            if (gi < p && gj < p) {
+                const double val = alpha * acc[u][reg];
+                Cg[ix(C.r, gi) + ix(C.c, gj)] = val;
+                if (t_r[u] != t_c[u]) Cg[ix(C.r, gj) + ix(C.c, gi)] = val;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ inline void wg_syrk(int p, int q, View A, View G, double alpha, double* lds) {
+    if (p > 128 || q > SYRK_QMAX) { wg_gemm(p, p, q, A, tview(A), G, alpha, 0.0, lds); return; }
+    GemmDesc* dsc = reinterpret_cast<GemmDesc*>(lds + GEMM_LDS_DOUBLES);
+    __syncthreads();                         // nobody still reads what the tiles / descriptor alias
+    if (threadIdx.x == 0) { dsc->m = p; dsc->n = p; dsc->k = q; dsc->pad = 0; dsc->A = A; dsc->C = G; dsc->alpha = alpha; dsc->beta = 0.0; dsc->amax = nullptr; }
+    __syncthreads();
+#if TTN_WG == 512
+    if (p > 64) wg_syrk_impl<3, 4, 5>(dsc, lds);         // 128 rows: chunks of 48 k (145 x 48 doubles), 36 tiles on 8 waves
+    else wg_syrk_impl<6, 2, 2>(dsc, lds);                // <= 64 rows: chunks of 96 k (81 x 96), 10 tiles
+#else
+    if (p > 64) wg_syrk_impl<6, 2, 3>(dsc, lds);         // 145 x 96 doubles, 36 tiles on 16 waves
+    else wg_syrk_impl<6, 1, 1>(dsc, lds);
+#endif
 }
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -1677,7 +1791,7 @@ struct CompressArgs {
     double jneg_mult;      // columns below jneg_mult * sqrt(m) * eps * max column norm are treated as zero
     int fast;              // 0: Householder route only; odd: try the Gram / factored fast paths (verified a posteriori) first.
                            // Diagnostic bits (TTN_FAST): 2 no eigensolver in route G (Cholesky + Jacobi), 4 none in route F,
-                           // 8 no diagonal-left shortcut in route F, 16 no Jacobi polish after a failed conditioning test,
+                           // 8 no diagonal-left shortcut in route F, 16 no Jacobi polish after a failed conditioning test, 32 no CholeskyQR2,
                            // 64 Gram / reflector / check matrices in their own scratch instead of the dead T buffer
     // fused apply (ttn_apply_compress): psi = A * x is never materialised.  During the FIRST L->R sweep core k+1 of psi
     // is still virtual (= A_{k+1} applied to x_{k+1}); psi's ranks already hold A.rks .* x.rks.
@@ -1688,6 +1802,7 @@ struct CompressArgs {
                            //    (_swap_adjacent_sites, src/qtt_tools.jl:680-685)
     int fused_first_real;  // fused bond range (k_single < 0, ascending): the left core of the first bond is already real (a boundary core
                            // imported from the left neighbour of a core-wise sharded chain); otherwise it is written out first
+    int prof_step;         // TTN_PROF_STEP: the phase counters of P.prof collect this step only (-1: every step)
     int* next_train;       // null: one workgroup per train (grid = batch).  Else a device counter (zeroed before the launch): the grid is
                            // PERSISTENT — workgroup w starts with train w and then pulls train gridDim.x + atomicAdd(next_train, 1)
                            // until the batch is exhausted (dynamic balancing of the data-dependent sweep counts, scratch per slot)
@@ -1709,6 +1824,100 @@ struct BondCtx {
     double *M, *M2, *Vb, *Wb, *Us, *Xg, *sig, *sigs, *Ga, *Gb, *Cc, *T1, *T2, *T3;
     int* perm;
 };
+
+// -------------------------------------------------------------------------------------------------
+// CholeskyQR2 for the rank-ramp bond steps (short side 16..64, moderately ill-conditioned: kappa 1e2..1e5 on the benchmark's
+// L->R step 64 x 384).  The Householder LQ of such a matrix is 64 dependent reflectors over 384 columns (1.75 M clk with two
+// workgroups per CU — more than a whole 128-row Gram step); the Gram route alone squares the condition number.  CholeskyQR2:
+//   L1 = chol(M M^T);  Q1 = L1^-1 M (forward substitution, backward stable column by column);  L2 = chol(Q1 Q1^T);  L = L1 L2.
+// Q1 is orthonormal up to eps kappa^2 << 1, so ITS Gram matrix loses nothing, and M = L1 Q1 + E with |E| <= eps |L1| |Q1|: L is
+// the triangular factor of M + dM, ||dM|| ~ eps ||M|| — the backward error of the Householder factorisation — as long as
+// eps kappa^2 stays well below 1 (measured: |Q1 Q1^T - I| <= CHOLQR_ORTH_MAX, i.e. kappa up to ~3e6); two MFMA Gram products, two
+// 64 x 64 factorisations in LDS and one triangular solve instead of the reflector chain.
+// -------------------------------------------------------------------------------------------------
+#define CHOLQR_PIVOT_MAX 1.0e11       // first-pass pivot ratio (a lower bound of kappa^2) up to which CholeskyQR2 is taken
+#define CHOLQR_ORTH_MAX 1.0e-3        // ... and the second pass must see a nearly orthonormal Q1: max |Q1 Q1^T - I| (~ eps kappa^2)
+#define CHOLQR_CHECK_TOL 1.0e-9       // a-posteriori |Rf Rf^T - Sigma| bound of the route (the Householder route it replaces has none)
+
+// p x p block of a leading-dimension-128 matrix in global memory -> rows [row_off, row_off + p) of the first p columns of the LDS image,
+// eight loads of a thread in flight; returns max |src - I| (every thread; contains barriers)
+__device__ __noinline__ double wg_img_load(double* img, int row_off, const double* src, int p, double* red) {
+    img = unip(img); src = unip(src); p = uni32(p); row_off = uni32(row_off); red = unip(red);
+    lds_f64* X = (lds_f64*)img;
+    double dev = 0.0;
+    wg_batched<8>((long long)p * p, [&](long long e) { const int ei = (int)e; return src[ei % p + 128 * (ei / p)]; },
+                  [&](long long e, double v) {
+                      const int ei = (int)e, i = ei % p, j = ei / p;
+                      X[row_off + i + 128 * j] = v;
+                      dev = fmax(dev, fabs(v - ((i == j) ? 1.0 : 0.0)));
+                  });
+    return unif64(wg_max(dev, red));
+}
+
+// Q[i][c] = (L^-1 (s M))[i][c], i < p, c < q: one thread per column, 16 rows at a time in registers; L (lower triangular, p <= 64) in
+// the LDS image (L[i][k] at img[i + 128 k]), M and Q row-major in global memory.  Ends with a barrier.
+__device__ __noinline__ void wg_trsm_lower_cols(int p, int q, const double* img, const double* M, long long ldm, double s_, double* Q, long long ldq) {
+    p = uni32(p); q = uni32(q); img = unip(img); M = unip(M); Q = unip(Q); ldm = uni64(ldm); ldq = uni64(ldq); s_ = unif64(s_);
+    const lds_f64* L = (const lds_f64*)img;
+    gmem_f64* Mg = (gmem_f64*)M;
+    gmem_wf64* Qg = (gmem_wf64*)Q;
+    for (int c = threadIdx.x; c < q; c += TTN_WG) {
+        for (int i0 = 0; i0 < p; i0 += 16) {
+            const int nb = (p - i0 < 16) ? p - i0 : 16;
+            double v[16];
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) v[ii] = Mg[(long long)(i0 + (ii < nb ? ii : 0)) * ldm + c];
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) v[ii] *= s_;
+            for (int j0 = 0; j0 < i0; j0 += 16) {            // the finished blocks of this column (the thread's own stores)
+                double qv[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) qv[jj] = Qg[(long long)(j0 + jj) * ldq + c];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj)
+#pragma unroll
+                    for (int ii = 0; ii < 16; ++ii) v[ii] = fma(-L[(j0 + jj) * 128 + i0 + ii], qv[jj], v[ii]);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < nb) {
+                    v[k] = v[k] / L[(i0 + k) * 128 + i0 + k];
+#pragma unroll
+                    for (int ii = k + 1; ii < 16; ++ii) v[ii] = fma(-L[(i0 + k) * 128 + i0 + ii], v[k], v[ii]);
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) if (ii < nb) Qg[(long long)(i0 + ii) * ldq + c] = v[ii];
+        }
+    }
+    __syncthreads();
+}
+
+// L = L1 L2 in the LDS image (p <= 64): L2 at img[i + 128 k], L1 at img[64 + i + 128 k] (the rows the p x p Jacobi image pads with
+// zeros); on exit the first p columns hold L (lower triangle) and zeros everywhere else.  Ends with a barrier.
+__device__ __noinline__ void wg_tril_mul_lds(int p, double* img) {
+    p = uni32(p); img = unip(img);
+    lds_f64* X = (lds_f64*)img;
+    constexpr int NE = (64 * 64 + TTN_WG - 1) / TTN_WG;
+    double acc[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int e = threadIdx.x + u * TTN_WG, i = e % p, j = e / p;
+        double a = 0.0;
+        if (e < p * p && i >= j)
+            for (int k = j; k <= i; ++k) a = fma(X[64 + i + 128 * k], X[k + 128 * j], a);
+        acc[u] = a;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < p * 128; e += TTN_WG) X[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int e = threadIdx.x + u * TTN_WG, i = e % p, j = e / p;
+        if (e < p * p && i >= j) X[i + 128 * j] = acc[u];
+    }
+    __syncthreads();
+}
 
 // Jacobi on the pj columns (length pj) of X, then singular values sigma_c = ||x_c|| sorted descending with a
 // stable order: perm[pos] = column, sigs[pos] = sigma (scaled units).  Returns the sweep count (<0: limit hit).
@@ -2096,7 +2305,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
     }
 
     long long t_prev = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
-#define PROF_MARK(slot) if (P.prof) { __syncthreads(); if (tid == 0) { long long t_now = (long long)__builtin_amdgcn_s_memtime(); P.prof[(long long)b * 16 + (slot)] += t_now - t_prev; t_prev = t_now; } }
+#define PROF_MARK(slot) if (P.prof) { __syncthreads(); if (tid == 0) { long long t_now = (long long)__builtin_amdgcn_s_memtime(); if (P.prof_step < 0 || P.prof_step == step) P.prof[(long long)b * 16 + (slot)] += t_now - t_prev; t_prev = t_now; } }
 
     const View Lfv = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));     // (mr x r)
     int route = 2;                                        // 0 = F, 1 = G, 2 = H (for the diagnostics)
@@ -2117,8 +2326,8 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         const View Ccv = mkview(S.Cc, plain(1), plain(128));
         bool diagA = false;
         if (ok) {
-            wg_gemm(rm, rm, p, tview(Ap), Ap, Gav, 1.0 / (sA * sA), 0.0, lds);          // A'^T A'
-            wg_gemm(rm, rm, q, Bp, tview(Bp), Gbv, 1.0 / (sB * sB), 0.0, lds);          // B' B'^T
+            wg_syrk(rm, p, tview(Ap), Gav, 1.0 / (sA * sA), lds);          // A'^T A'
+            wg_syrk(rm, q, Bp, Gbv, 1.0 / (sB * sB), lds);          // B' B'^T
             PROF_MARK(8)
             // A' = U D^(1/2) with orthonormal U (the left core of a bond step is left as U sqrt(S) by the step before it, so every
             // R->L step of a sweep that follows an L->R sweep sees this): then M = U (D^(1/2) B') and the SVD of M is U times the SVD
@@ -2241,8 +2450,8 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             wg_gemm(rk, q, rm, tview(mkview(S.T3, plain(1), plain(128))), Bp, Rft, 1.0, 0.0, lds);
             }
             // a-posteriori check: Lf^T Lf = Sigma, Rf Rf^T = Sigma
-            wg_gemm(rk, rk, p, tview(Lft), Lft, mkview(S.T1, plain(1), plain(128)), 1.0, 0.0, lds);
-            wg_gemm(rk, rk, q, Rft, tview(Rft), mkview(S.T2, plain(1), plain(128)), 1.0, 0.0, lds);
+            wg_syrk(rk, p, tview(Lft), mkview(S.T1, plain(1), plain(128)), 1.0, lds);
+            wg_syrk(rk, q, Rft, mkview(S.T2, plain(1), plain(128)), 1.0, lds);
             const double e1 = wg_check_diag(S, S.T1, 128, rk, s0);
             const double e2 = wg_check_diag(S, S.T2, 128, rk, s0);
             ok = (e1 <= FAST_CHECK_TOL) && (e2 <= FAST_CHECK_TOL);
@@ -2306,15 +2515,20 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         const bool lq_in_lds = (long long)p * q <= GEMM_LDS_DOUBLES || GEMM_LDS_DOUBLES / p >= 2 * p;     // whole, or TSQR chunks (wg_lq_blocked)
         const bool eig_ok = SWAP == 0 && P.fast && !(P.fast & 2) && need_lq && ((p > 64 && p <= 128 && P.max_bond <= 64) || (p == 64 && P.max_bond < 64));
         // (the eigensolver leaves its image — at most 64 columns — in LDS whatever p is; the Cholesky + Jacobi form needs the whole L there)
-        for (int attempt = (SWAP == 0 && P.fast && need_lq && (eig_ok || (x_in_lds && !lq_in_lds)) && p >= 2) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
+        // CholeskyQR2 (above) instead of the Householder LQ when the plain Gram route finds the matrix too ill-conditioned for itself
+        // (only where the Householder LQ cannot keep the whole matrix in LDS — 64 x 384, 32 x 384: there it wins 3x; against the in-LDS
+        // LQ of a 64 x 128 step it is a draw, and the R->L ramp matrices are often too ill-conditioned for it anyway)
+        const bool cholqr_ok = SWAP == 0 && P.fast && !(P.fast & 32) && need_lq && x_in_lds && p >= 16 && p <= 64 && (long long)p * q > GEMM_LDS_DOUBLES;
+        for (int attempt = (SWAP == 0 && P.fast && need_lq && (eig_ok || cholqr_ok || (x_in_lds && !lq_in_lds)) && p >= 2) ? 1 : 2; attempt <= 2 && !done; ++attempt) {
             bool ok = true;
             bool use_eig = false;
+            bool cholqr = false;
             double gram_trace = 0.0;
             X = (x_in_lds || attempt == 1) ? S.ldsX : S.Xg;
             ldx = (x_in_lds || attempt == 1) ? 128 : p;
             if (attempt == 1) {
                 // =========================== route G: L = chol(M M^T) ===========================
-                wg_gemm(p, p, q, Mv, tview(Mv), mkview(S.Ga, plain(1), plain(128)), inv_s0 * inv_s0, 0.0, lds);
+                wg_syrk(p, q, Mv, mkview(S.Ga, plain(1), plain(128)), inv_s0 * inv_s0, lds);
                 PROF_MARK(7)
                 // p = 128 with at most 64 vectors kept (the L->R steps of the benchmark sweep): eigen-decomposition of the Gram
                 // matrix itself — tridiagonalisation, bisection, twisted factorisations (ttn_eig_kernels.h) — instead of
@@ -2338,15 +2552,34 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                     __syncthreads();
                     PROF_MARK(11)
                 } else {
-                for (int e = tid; e < p * 128; e += TTN_WG) if ((e & 127) < p) S.ldsX[e] = S.Ga[e];
-                __syncthreads();
+                wg_img_load(S.ldsX, 0, S.Ga, p, S.red);
                 ok = wg_chol_lds128(p, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
-                // with truncerr > 0 the rank rule reads the SMALL singular values too: need cond(M) <= kappa_max overall
-                if (ok && P.truncerr > 0.0 && S.scal[1] > FAST_KAPPA_MAX * FAST_KAPPA_MAX) ok = false;
+                // with truncerr > 0 the rank rule reads the SMALL singular values too: need cond(M) <= kappa_max overall;
                 // likewise when nothing will be truncated (p <= max_bond: every singular value is kept): the pivot ratio is a lower
-                // bound of cond(M)^2, so a value above the limit means the a-posteriori test WILL fail — go to Householder now
-                // instead of after a wasted Jacobi (the rank-ramp steps of a sweep are such steps)
-                if (ok && (long long)p <= P.max_bond && S.scal[1] > FAST_KAPPA_MAX * FAST_KAPPA_MAX) ok = false;
+                // bound of cond(M)^2, so a value above the limit means the a-posteriori test WILL fail — take the factor from
+                // CholeskyQR2 (the rank-ramp steps of a sweep are such steps), or go to Householder now instead of after a wasted Jacobi
+                // The pivot ratio is only a LOWER bound of cond(M)^2 (unpivoted: orders of magnitude low on the R->L ramp matrices), so a
+                // step that may take CholeskyQR2 always does: its second pass measures the conditioning itself.
+                if (ok && (P.truncerr > 0.0 || (long long)p <= P.max_bond)) {
+                    if (cholqr_ok) { if (unif64(S.scal[1]) <= CHOLQR_PIVOT_MAX) cholqr = true; else ok = false; }
+                    else if (unif64(S.scal[1]) > FAST_KAPPA_MAX * FAST_KAPPA_MAX) ok = false;
+                }
+                if (cholqr) {
+                    for (int e = tid; e < p * p; e += TTN_WG) { const int i = e % p, j = e / p; S.T1[i + 128 * j] = S.ldsX[i + 128 * j]; }       // L1 (the GEMM below takes the image)
+                    wg_trsm_lower_cols(p, q, S.ldsX, S.M, q, inv_s0, S.M2, q);                                                           // Q1 = L1^-1 M / s0
+                    PROF_MARK(8)
+                    const View Q1v = mkview(S.M2, plain(q), plain(1));
+                    wg_syrk(p, q, Q1v, mkview(S.Cc, plain(1), plain(128)), 1.0, lds);
+                    PROF_MARK(9)
+                    // Q1 Q1^T = I + E, |E| ~ eps cond(M)^2: the route needs |E| << 1 (CHOLQR_ORTH_MAX), else Householder
+                    const double dev = wg_img_load(S.ldsX, 0, S.Cc, p, S.red);
+                    ok = dev <= CHOLQR_ORTH_MAX && wg_chol_lds128(p, S.ldsX, S.red, S.iflag, S.scal + 1) == 0;
+                    if (ok) {
+                        wg_img_load(S.ldsX, 64, S.T1, p, S.red);
+                        wg_tril_mul_lds(p, S.ldsX);
+                    }
+                    PROF_MARK(10)
+                }
                 for (int e = tid; e < p * 128; e += TTN_WG) if ((e & 127) >= p) S.ldsX[e] = 0.0;      // zero row padding for the Jacobi
                 __syncthreads();
                 PROF_MARK(11)
@@ -2408,7 +2641,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 done = true;
                 continue;
             }
-            if (attempt == 1) {
+            if (attempt == 1 && !cholqr) {
                 // Gram route: the KEPT block must be well conditioned (error ~ eps*kappa^2, verified below); the discarded
                 // singular values only matter to the rank rule, i.e. when truncerr > 0 (then all of them must qualify).
                 const int rl = (P.truncerr > 0.0) ? p : r;
@@ -2502,9 +2735,9 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             __syncthreads();
             wg_gemm(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, Ro, inv_s0, 0.0, lds);
             if (attempt == 1) {
-                wg_gemm(r, r, q, Ro, tview(Ro), mkview(S.T2, plain(1), plain(128)), 1.0, 0.0, lds);
+                wg_syrk(r, q, Ro, mkview(S.T2, plain(1), plain(128)), 1.0, lds);
                 const double e2 = unif64(wg_check_diag(S, S.T2, 128, r, s0));
-                if (!(e2 <= FAST_CHECK_TOL)) continue;                     // redo with Householder (M is intact)
+                if (!(e2 <= (cholqr ? CHOLQR_CHECK_TOL : FAST_CHECK_TOL))) continue;                     // redo with Householder (M is intact)
                 if (P.sv_out && step < P.sv_steps) {
                     double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
                     for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? S.sigs[i] * s0 : -1.0;
@@ -2755,9 +2988,10 @@ __global__ void TTN_KERNEL_BOUNDS k_dot(DotArgs P) {
 __global__ void TTN_KERNEL_BOUNDS k_selftest_gemm(int m, int n, int k, double* A, double* B, double* C, double alpha,
                                                          double beta, int ta, int tb) {
     extern __shared__ double lds[];
-    const View Av = ta ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));     // ta: A stored k x m
+    const View Av = (ta & 1) ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));     // ta & 1: A stored k x m
     const View Bv = tb ? mkview(B, plain(1), plain(k)) : mkview(B, plain(n), plain(1));     // tb: B stored n x k
-    wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), alpha, beta, lds);
+    if (ta & 2) wg_syrk(m, k, Av, mkview(C, plain(n), plain(1)), alpha, lds);               // ta & 2: C = alpha A A^T (n == m; B, beta unused)
+    else wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), alpha, beta, lds);
 }
 
 __global__ void TTN_KERNEL_BOUNDS k_bench_gemm(int m, int n, int k, double* A, double* B, double* C, int ta, int tb, int reps,
@@ -2766,11 +3000,14 @@ __global__ void TTN_KERNEL_BOUNDS k_bench_gemm(int m, int n, int k, double* A, d
     // every workgroup of the grid works on its own copy of the operands (the buffers hold gridDim.x of them back to back): a grid
     // of 2 x #CUs measures the GEMM with a second workgroup resident on the CU
     A += (long long)blockIdx.x * m * k; B += (long long)blockIdx.x * k * n; C += (long long)blockIdx.x * m * n;
-    const View Av = ta ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));
+    const View Av = (ta & 1) ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));
     const View Bv = tb ? mkview(B, plain(1), plain(k)) : mkview(B, plain(n), plain(1));
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
-    for (int r = 0; r < reps; ++r) wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), 1.0, 0.0, lds);
+    for (int r = 0; r < reps; ++r) {
+        if (ta & 2) wg_syrk(m, k, Av, mkview(C, plain(n), plain(1)), 1.0, lds);            // the Gram-product routine (n == m)
+        else wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), 1.0, 0.0, lds);
+    }
     __syncthreads();
     const long long t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = t1 - t0;

@@ -16,7 +16,7 @@ def T():
 
 
 def _gemm(T, A, B, C0, alpha, beta, ta, tb):
-    m, k = (A.shape[1], A.shape[0]) if ta else A.shape
+    m, k = (A.shape[1], A.shape[0]) if (ta & 1) else A.shape
     n = B.shape[0] if tb else B.shape[1]
     A = np.ascontiguousarray(A, dtype=np.float64)
     B = np.ascontiguousarray(B, dtype=np.float64)
@@ -39,6 +39,19 @@ def test_wg_gemm_exact_on_integers(T, m, n, k, ta, tb):
     assert np.array_equal(got, ref)
     got0 = _gemm(T, A.T if ta else A, B.T if tb else B, np.full((m, n), np.nan), 1.0, 0.0, ta, tb)   # beta = 0 must not read C
     assert np.array_equal(got0, A @ B)
+
+
+@pytest.mark.parametrize("p,q", [(128, 384), (64, 384), (96, 200), (16, 192), (64, 1280), (33, 50), (128, 48), (1, 7), (128, 3000), (130, 64)])
+@pytest.mark.parametrize("ta", [0, 1])
+@pytest.mark.parametrize("wg512", [0, 1])
+def test_wg_syrk_exact_on_integers(T, monkeypatch, p, q, ta, wg512):
+    """G = alpha A A^T by the Gram-product routine (one staging per K chunk, lower-triangle tiles, both triangles written),
+    both builds; shapes beyond its limits (p > 128, q above the offset table) take the general GEMM."""
+    monkeypatch.setenv("TTN_WG512_SELFTEST", str(wg512))
+    rng = np.random.default_rng(p * 100 + q)
+    A = rng.integers(-8, 9, size=(p, q)).astype(np.float64)
+    got = _gemm(T, A.T if ta else A, np.zeros((q, p)), np.full((p, p), np.nan), 0.5, 0.0, 2 | ta, 0)
+    assert np.array_equal(got, 0.5 * (A @ A.T))
 
 
 def test_wg_gemm_random_fp64(T):
