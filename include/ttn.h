@@ -264,6 +264,7 @@ int ttn_bench_lds(int what, int64_t n, int64_t reps, int64_t* cycles_out, int64_
 int ttn_prof_get(int64_t b, int64_t* out8);
 /* per bond step (first 120 steps): (p << 32) | jacobi_sweeps, p = short side of the merged matrix */
 int ttn_prof_steps(int64_t b, int64_t* out120);
+int ttn_prof_fine(int64_t b, int64_t* out64);       /* TTN_PROF_STEP=k: 64 fine-grained cycle counters of bond step k of train b */
 
 /* ---- stateless host-pointer entry points: the literal drop-ins for one train --------------------
  * Each uploads, runs the handle op above, and downloads.  Output cores are caller-allocated:

@@ -97,6 +97,7 @@ SIGNATURES = {
     "ttn_selftest_gemm": (C.c_int, [i64, i64, i64, p_f64, p_f64, p_f64, C.c_double, C.c_double, C.c_int, C.c_int]),
     "ttn_prof_get": (C.c_int, [i64, p_i64]),
     "ttn_prof_steps": (C.c_int, [i64, p_i64]),
+    "ttn_prof_fine": (C.c_int, [i64, p_i64]),
     "ttn_event_record": (C.c_int, [i64]),
     "ttn_event_elapsed": (C.c_int, [i64, i64, C.POINTER(C.c_float)]),
     "ttn_apply_f64": (C.c_int, [i64, p_i64, pp_f64, p_i64, pp_f64, p_i64, pp_f64]),

@@ -752,8 +752,8 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     { const char* e = getenv("TTN_PROF_STEP"); P.prof_step = e ? atoi(e) : -1; }
     if (getenv("TTN_PROF")) {
         static long long* d_prof = nullptr; static int prof_cap = 0;
-        if (prof_cap < psi->batch) { if (d_prof) hipFree(d_prof); HIPCHK(hipMalloc((void**)&d_prof, sizeof(long long) * 136 * psi->batch)); prof_cap = psi->batch; }
-        HIPCHK(hipMemsetAsync(d_prof, 0, sizeof(long long) * 136 * psi->batch, g_stream));
+        if (prof_cap < psi->batch) { if (d_prof) hipFree(d_prof); HIPCHK(hipMalloc((void**)&d_prof, sizeof(long long) * 200 * psi->batch)); prof_cap = psi->batch; }
+        HIPCHK(hipMemsetAsync(d_prof, 0, sizeof(long long) * 200 * psi->batch, g_stream));
         g_prof_batch = psi->batch;
         P.prof = d_prof; g_prof = d_prof;
     }
@@ -1407,6 +1407,17 @@ int ttn_prof_steps(int64_t b, int64_t* out120) {
     HIPCHK(hipMemcpyAsync(tmp, g_prof + 16LL * g_prof_batch + 120 * b, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     for (int i = 0; i < 120; ++i) out120[i] = tmp[i];
+    return TTN_OK;
+}
+
+int ttn_prof_fine(int64_t b, int64_t* out64) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!g_prof || !out64) return fail(TTN_ERR_ARG, "no profile (set TTN_PROF=1)");
+    long long tmp[64];
+    HIPCHK(hipMemcpyAsync(tmp, g_prof + 136LL * g_prof_batch + 64 * b, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (int i = 0; i < 64; ++i) out64[i] = tmp[i];
     return TTN_OK;
 }
 

@@ -716,6 +716,104 @@ __device__ inline void wg_syrk(int p, int q, View A, View G, double alpha, doubl
 #endif
 }
 
+// -------------------------------------------------------------------------------------------------
+// wg_gemm_ra: C = alpha * A B for a SHORT, SHALLOW A (m <= 64 rows, k <= 128) and any n — the right factor of a bond step
+// (sqrt(S) V^T = X^T M: 64 x 384 x 128), route F's two output products (64 x 128 x 64; the left one is passed transposed).
+// Every wave keeps the A fragments of its 16-row tile for ALL of k in registers (k/4 doubles per lane, read once), B streams through
+// LDS in chunks of 16 x (NWAVES / 4) columns — all of k at once, so one barrier pair per chunk of k/4 MFMAs per wave instead of
+// one per 16 k, no A staging at all, and the loads of the next chunk are in flight (registers) during the MFMAs.  The general
+// tiled GEMM ran these shapes at 21 % of the matrix pipe with two workgroups per CU.
+// -------------------------------------------------------------------------------------------------
+#define GEMM_RA_NMAX (2 * GEMM_TAB_ENTRIES - 320)           // column offsets of B tabulated once
+__device__ TTN_NI_GEMM void wg_gemm_ra_impl(const GemmDesc* dsc_, double* lds) {
+    const lds_gdesc* dsc = (const lds_gdesc*)dsc_;
+    constexpr int CG = TTN_NWAVES / 4, NC = 16 * CG;                // column groups of waves; columns per chunk (32 / 64)
+    constexpr int LD = (NC == 32) ? 49 : 81;                       // == 17 mod 32
+    constexpr int KR = 128 / (TTN_WG / NC);                         // k rows per thread of a chunk (8)
+    static_assert(128 * LD <= GEMM_LDS_DOUBLES, "a chunk holds all of k");
+    const int m = uni32(dsc->m), n = uni32(dsc->n), k = uni32(dsc->k);
+    const View A = ldsView(&dsc->A), B = ldsView(&dsc->B), C = ldsView(&dsc->C);
+    const double alpha = unif64(dsc->alpha);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int rt = uni32(wave & 3), cg = uni32(wave >> 2);
+    lds_f64* Bs = (lds_f64*)lds;                                    // Bs[kk * LD + j]
+    lds_i32* rowA = (lds_i32*)(lds + GEMM_LDS_DOUBLES + 32);       // 64
+    lds_i32* kA = rowA + 64;                                        // 128
+    lds_i32* kB = kA + 128;                                         // 128
+    lds_i32* colB = kB + 128;                                       // n
+    for (int i = tid; i < 64; i += TTN_WG) rowA[i] = (i < m) ? (int)ix(A.r, i) : 0;
+    for (int i = tid; i < 128; i += TTN_WG) { kA[i] = (i < k) ? (int)ix(A.c, i) : 0; kB[i] = (i < k) ? (int)ix(B.r, i) : 0; }
+    for (int i = tid; i < n; i += TTN_WG) colB[i] = (int)ix(B.c, i);
+    __syncthreads();
+    gmem_f64* Ag = (gmem_f64*)A.p;
+    gmem_f64* Bg = (gmem_f64*)B.p;
+    gmem_wf64* Cg = (gmem_wf64*)C.p;
+    const int ksteps = (k + 3) >> 2;
+    double areg[32];
+    {
+        const int row = rt * 16 + li, ro = rowA[row < 64 ? row : 0];
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            const int kk = 4 * ks + lk;
+            areg[ks] = Ag[(row < m && kk < k) ? ro + kA[kk] : 0];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) { const int kk = 4 * ks + lk; if (!(row < m && kk < k)) areg[ks] = 0.0; }
+    }
+    const int fx = tid % NC, sy = tid / NC;                         // column of the chunk; first k row (rows sy + (TTN_WG / NC) u)
+    double v[KR];
+#define RA_LOAD(C0)                                                                                                     \
+    {                                                                                                                   \
+        const int col = (C0) + fx;                                                                                      \
+        const int co = (col < n) ? colB[col] : 0;                                                                       \
+        _Pragma("unroll") for (int u = 0; u < KR; ++u) {                                                                 \
+            const int kk = sy + (TTN_WG / NC) * u;                                                                      \
+            v[u] = Bg[(col < n && kk < k) ? co + kB[kk] : 0];                                                           \
+        }                                                                                                               \
+    }
+    RA_LOAD(0)
+    const bool live = rt * 16 < m;                                  // wave-uniform
+    for (int c0 = 0; c0 < n; c0 += NC) {
+#pragma unroll
+        for (int u = 0; u < KR; ++u) {
+            const int kk = sy + (TTN_WG / NC) * u;
+            Bs[kk * LD + fx] = (c0 + fx < n && kk < k) ? v[u] : 0.0;
+        }
+        __syncthreads();
+        if (c0 + NC < n) RA_LOAD(c0 + NC)
+        if (live && c0 + cg * 16 < n) {
+            mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+            const lds_f64* bp = Bs + lk * LD + cg * 16 + li;
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks)
+                if (ks < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[ks], bp[4 * ks * LD], acc, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gi = rt * 16 + lk + 4 * reg, gj = c0 + cg * 16 + li;
+                if (gi < m && gj < n) Cg[ix(C.r, gi) + ix(C.c, gj)] = alpha * acc[reg];
+            }
+        }
+        __syncthreads();
+    }
+#undef RA_LOAD
+}
+
+// C = alpha A B; takes the register-A form when the shape allows (m <= 64, k <= 128), else the general GEMM
+__device__ inline void wg_gemm_ra(int m, int n, int k, View A, View B, View C, double alpha, double* lds) {
+#if TTN_WG != 512
+    // (measured: inside the 1024-thread kernel — one workgroup per CU, 16 waves — the general forms are as fast or faster)
+    wg_gemm(m, n, k, A, B, C, alpha, 0.0, lds);
+#else
+    if (m > 64 || k > 128 || n > GEMM_RA_NMAX || n < 64) { wg_gemm(m, n, k, A, B, C, alpha, 0.0, lds); return; }
+    GemmDesc* dsc = reinterpret_cast<GemmDesc*>(lds + GEMM_LDS_DOUBLES);
+    __syncthreads();
+    if (threadIdx.x == 0) { dsc->m = m; dsc->n = n; dsc->k = k; dsc->pad = 0; dsc->A = A; dsc->B = B; dsc->C = C; dsc->alpha = alpha; dsc->beta = 0.0; dsc->amax = nullptr; }
+    __syncthreads();
+    wg_gemm_ra_impl(dsc, lds);
+#endif
+}
+
 // sum over the 16 lanes of a DPP row, result in every lane of the row
 __device__ inline double fast_rcp(double x) {       // ~2^-50 relative after one Newton step
     double y = __builtin_amdgcn_rcp(x);
@@ -1919,6 +2017,120 @@ __device__ __noinline__ void wg_tril_mul_lds(int p, double* img) {
     __syncthreads();
 }
 
+// -------------------------------------------------------------------------------------------------
+// Element loops of a bond step that scale the image columns by functions of sigma_j.  Written inline as
+// `for (e = tid; e < p * r; e += WG) { row = e % p; j = e / p; ... sqrt(sigs[j]) ... ix(view, row) ... }` they spent ~3 k clk per
+// element of a thread on two runtime integer divisions, the two-level index of the output view, an fp64 square root and two fp64
+// divisions (57 k clk per 128-row Gram step for 8192 elements).  Out of line: everything that depends on j alone (factors, the
+// permutation, column offsets) or on the row alone (row offsets) goes to small LDS tables first, the element loop walks (row = lane,
+// j = wave) without divisions.  `tab`: 512 doubles of LDS (the Householder panel matrices S.Ts / S.Ss, dead outside the LQ).
+// -------------------------------------------------------------------------------------------------
+// Lo[row, j] = keep_j ? X[row, perm_j] f1_j : 0,  Us[j p + row] = keep_j ? X[row, perm_j] f2_j : 0   (row < p <= 128, j < r <= 128)
+//   mode 0 (tt_compress!):  f1 = sq0 / sqrt(s_j), f2 = sq0 / (s_j sqrt(s_j));  mode 1 (swap, wide): 1 / s_j, s0 / s_j;  mode 2 (swap, tall): s0, 1 / s_j^2
+__device__ __noinline__ void wg_scale_image(const double* X, int ldx, int x_in_lds, const double* sigs, const int* perm, View Lo, double* Us, int p, int r,
+                                            double s0, double aneg, int mode, double* tab) {
+    X = unip(X); ldx = uni32(ldx); x_in_lds = uni32(x_in_lds); sigs = unip(sigs); perm = unip(perm); Lo = uniView(Lo); Us = unip(Us);
+    p = uni32(p); r = uni32(r); s0 = unif64(s0); aneg = unif64(aneg); mode = uni32(mode); tab = unip(tab);
+    lds_f64* f1 = (lds_f64*)tab; lds_f64* f2 = f1 + 128;
+    lds_i32* pj = (lds_i32*)(f2 + 128); lds_i32* coff = pj + 128; lds_i32* roff = coff + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double sq0 = sqrt(s0);
+    for (int j = tid; j < r; j += TTN_WG) {
+        const double sj = sigs[j];
+        const bool keep = (sj > 0.0) && (sj * sj > aneg);
+        double a, b_;
+        if (mode == 0) { const double rs = sqrt(sj); a = sq0 / rs; b_ = sq0 / (sj * rs); }
+        else if (mode == 1) { a = 1.0 / sj; b_ = s0 / sj; }
+        else { a = s0; b_ = 1.0 / (sj * sj); }
+        f1[j] = keep ? a : 0.0; f2[j] = keep ? b_ : 0.0;
+        pj[j] = perm[j]; coff[j] = (int)ix(Lo.c, j);
+    }
+    for (int i = tid; i < p; i += TTN_WG) roff[i] = (int)ix(Lo.r, i);
+    __syncthreads();
+    gmem_wf64* Lg = (gmem_wf64*)Lo.p;
+    gmem_wf64* Ug = (gmem_wf64*)Us;
+    for (int j = wave; j < r; j += TTN_NWAVES) {
+        const double a = f1[j], b_ = f2[j];
+        const int c = pj[j], co = coff[j];
+        for (int row = lane; row < p; row += 64) {
+            const double xv = x_in_lds ? ((const lds_f64*)X)[c * ldx + row] : X[(long long)c * ldx + row];
+            Lg[roff[row] + co] = xv * a;
+            Ug[j * p + row] = xv * b_;
+        }
+    }
+    __syncthreads();
+}
+
+// max over i, j < r of |D[i + ldd j] - delta_ij sigs[i] s0| / (s0 sqrt(sigs[i] sigs[j]))   (r <= 128; every thread gets it)
+__device__ __noinline__ double wg_check_diag_tab(const double* sigs, const double* D, int ldd, int r, double s0, double* tab, double* red) {
+    sigs = unip(sigs); D = unip(D); ldd = uni32(ldd); r = uni32(r); s0 = unif64(s0); tab = unip(tab); red = unip(red);
+    lds_f64* t = (lds_f64*)tab; lds_f64* ref = t + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < r; i += TTN_WG) { const double si = sigs[i]; t[i] = 1.0 / sqrt(s0 * si); ref[i] = si * s0; }
+    __syncthreads();
+    gmem_f64* Dg = (gmem_f64*)D;
+    double worst = 0.0;
+    for (int j = wave; j < r; j += TTN_NWAVES) {
+        const double tj = t[j];
+        for (int i = lane; i < r; i += 64) {
+            const double dv = Dg[i + ldd * j];
+            const double dev = fabs(dv - ((i == j) ? ref[i] : 0.0)) * (t[i] * tj);
+            worst = fmax(worst, dev);
+        }
+    }
+    return unif64(wg_max(worst, red));
+}
+
+// Route F with a 64 x 64 left Gram matrix Ga (ld 128): w = max_{i != j} |Ga_ij| / sqrt(Ga_ii Ga_jj) (1 if a diagonal entry is not
+// positive) and T3 = D^(1/2) Gb D^(1/2), D = diag(Ga) — one pass over both matrices.  Every thread gets w.
+__device__ __noinline__ double wg_diag_test_t3(const double* Ga, const double* Gb, double* T3, double* tab, double* red) {
+    Ga = unip(Ga); Gb = unip(Gb); T3 = unip(T3); tab = unip(tab); red = unip(red);
+    lds_f64* sd = (lds_f64*)tab; lds_f64* isd = sd + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    gmem_f64* Gag = (gmem_f64*)Ga; gmem_f64* Gbg = (gmem_f64*)Gb; gmem_wf64* Tg = (gmem_wf64*)T3;
+    for (int i = tid; i < 64; i += TTN_WG) { const double d = Gag[i * 129]; const double sq = (d > 0.0) ? sqrt(d) : 0.0; sd[i] = sq; isd[i] = (d > 0.0) ? 1.0 / sq : -1.0; }
+    __syncthreads();
+    double w = 0.0;
+    const double si = sd[lane], ii = isd[lane];
+    constexpr int NJ = 64 / TTN_NWAVES;                       // columns per wave (8 / 4)
+    double ga[NJ], gb[NJ];
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) { const int j = wave + TTN_NWAVES * u; ga[u] = Gag[lane + 128 * j]; gb[u] = Gbg[lane + 128 * j]; }
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) {
+        const int j = wave + TTN_NWAVES * u;
+        const double ij = isd[j];
+        if (lane != j) w = fmax(w, (ii > 0.0 && ij > 0.0) ? fabs(ga[u]) * (ii * ij) : 1.0);
+        Tg[lane + 128 * j] = si * gb[u] * sd[j];
+    }
+    w = unif64(wg_max(w, red));
+    return w;
+}
+
+// Route F, diagonal-left form: T1[j 128 + row] = X[row, perm_j] fa / (sd_row sqrt(s_j)),  T2[j 128 + row] = X[row, perm_j] sd_row fb / (s_j sqrt(s_j)),
+// sd_row = sqrt(Ga[row, row]); row < 64, j < rk <= 64; X = the LDS image (ld 128)
+__device__ __noinline__ void wg_scale_t12_diag(const double* img, const double* sigs, const int* perm, const double* Ga, double* T1, double* T2, int rk,
+                                               double fa, double fb, double* tab) {
+    img = unip(img); sigs = unip(sigs); perm = unip(perm); Ga = unip(Ga); T1 = unip(T1); T2 = unip(T2); rk = uni32(rk); fa = unif64(fa); fb = unif64(fb); tab = unip(tab);
+    lds_f64* c1 = (lds_f64*)tab; lds_f64* c2 = c1 + 64; lds_f64* sd = c2 + 64; lds_f64* isd = sd + 64;
+    lds_i32* pj = (lds_i32*)(isd + 64);
+    const lds_f64* X = (const lds_f64*)img;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = tid; j < 64; j += TTN_WG) {
+        const double d = sqrt(Ga[j * 129]); sd[j] = d; isd[j] = 1.0 / d;
+        if (j < rk) { const double sj = sigs[j], rs = sqrt(sj); c1[j] = fa / rs; c2[j] = fb / (sj * rs); pj[j] = perm[j]; }
+    }
+    __syncthreads();
+    gmem_wf64* T1g = (gmem_wf64*)T1; gmem_wf64* T2g = (gmem_wf64*)T2;
+    const double sdr = sd[lane], isdr = isd[lane];
+    for (int j = wave; j < rk; j += TTN_NWAVES) {
+        const double xv = X[pj[j] * 128 + lane];
+        T1g[j * 128 + lane] = xv * (c1[j] * isdr);
+        T2g[j * 128 + lane] = xv * (sdr * c2[j]);
+    }
+    __syncthreads();
+}
+
 // Jacobi on the pj columns (length pj) of X, then singular values sigma_c = ||x_c|| sorted descending with a
 // stable order: perm[pos] = column, sigs[pos] = sigma (scaled units).  Returns the sweep count (<0: limit hit).
 __device__ int wg_svd_cols(const CompressArgs& P, const BondCtx& S, int pj, double* X, int ldx, bool in_lds, int mlen = 0) {
@@ -2305,6 +2517,9 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
     }
 
     long long t_prev = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    // fine-grained marks of ONE step (TTN_PROF_STEP): 64 more counters per train behind the phase and step tables
+#define FINE_MARK(id) if (P.prof && P.prof_step == step) { __syncthreads(); if (tid == 0) { long long t_now = (long long)__builtin_amdgcn_s_memtime(); P.prof[(long long)P.tt.batch * 136 + (long long)b * 64 + (id)] += t_now - t_fine; t_fine = t_now; } }
+    long long t_fine = t_prev;
 #define PROF_MARK(slot) if (P.prof) { __syncthreads(); if (tid == 0) { long long t_now = (long long)__builtin_amdgcn_s_memtime(); if (P.prof_step < 0 || P.prof_step == step) P.prof[(long long)b * 16 + (slot)] += t_now - t_prev; t_prev = t_now; } }
 
     const View Lfv = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));     // (mr x r)
@@ -2318,6 +2533,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         double sa = 0.0, sb = 0.0;
         sa = wg_absmax(ck, (long long)n1 * Dl * rm, S.red);
         sb = wg_absmax(ck1, (long long)n2 * rm * Dr, S.red);
+        FINE_MARK(0)
         bool ok = (sa > 0.0) && (sb > 0.0);
         const double sA = wide ? sa : sb, sB = wide ? sb : sa;       // scale of A', B'
         const double s0 = sA * sB;
@@ -2327,21 +2543,16 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         bool diagA = false;
         if (ok) {
             wg_syrk(rm, p, tview(Ap), Gav, 1.0 / (sA * sA), lds);          // A'^T A'
+            FINE_MARK(1)
             wg_syrk(rm, q, Bp, Gbv, 1.0 / (sB * sB), lds);          // B' B'^T
+            FINE_MARK(2)
             PROF_MARK(8)
             // A' = U D^(1/2) with orthonormal U (the left core of a bond step is left as U sqrt(S) by the step before it, so every
             // R->L step of a sweep that follows an L->R sweep sees this): then M = U (D^(1/2) B') and the SVD of M is U times the SVD
             // of the rm x q matrix N = D^(1/2) B' — no Cholesky factors, no core matrix, two output GEMMs instead of five.
             // Detected, not assumed: |G_ij| <= FAST_DIAG_TOL sqrt(G_ii G_jj) for every off-diagonal entry of A'^T A'.
             if (rm == 64 && !(P.fast & 4) && !(P.fast & 8)) {
-                double w = 0.0;
-                for (int e = tid; e < 64 * 64; e += TTN_WG) {
-                    const int i = e & 63, j = e >> 6;
-                    const double dii = S.Ga[i * 129], djj = S.Ga[j * 129];
-                    const double v = (dii > 0.0 && djj > 0.0) ? fabs(S.Ga[i + 128 * j]) / sqrt(dii * djj) : 1.0;
-                    if (i != j) w = fmax(w, v);
-                }
-                const double wmax = unif64(wg_max(w, S.red));
+                const double wmax = wg_diag_test_t3(S.Ga, S.Gb, S.T3, S.Ss, S.red);      // (T3 = D^(1/2) (B' B'^T) D^(1/2), used if the test passes)
                 diagA = wmax <= FAST_DIAG_TOL;
                 if (P.prof && tid == 0) {            // diagnostics: largest off-diagonal level seen (1e-18 units), steps tested / taken
                     long long* pf = P.prof + (long long)b * 16;
@@ -2350,13 +2561,10 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                     pf[13] += 1; pf[14] += diagA ? 1 : 0;
                 }
             }
+            FINE_MARK(3)
             if (diagA) {
-                // Gram matrix of N: D^(1/2) (B' B'^T) D^(1/2) -> T3
-                for (int e = tid; e < 64 * 64; e += TTN_WG) {
-                    const int i = e & 63, j = e >> 6;
-                    S.T3[i + 128 * j] = sqrt(S.Ga[i * 129]) * S.Gb[i + 128 * j] * sqrt(S.Ga[j * 129]);
-                }
-                __syncthreads();
+                // (the Gram matrix of N = D^(1/2) B', D^(1/2) (B' B'^T) D^(1/2), is in T3 already)
+                FINE_MARK(4)
             } else if (rm <= TTN_LDS_COLS / 2) {
                 // both Cholesky factorisations at once, one per half of the workgroup (wg_chol2_lds128)
                 for (int e = tid; e < rm * 128; e += TTN_WG) if ((e & 127) < rm) { S.ldsX[e] = S.Ga[e]; S.ldsX[TTN_LDS_IMG / 2 + e] = S.Gb[e]; }
@@ -2386,6 +2594,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             int nsw = 1;
             if (diagA) {
                 ok = wg_eig64(S.T3, 128, S.T2, 64, 64, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64) == 0;
+                FINE_MARK(5)
                 for (int j = tid; j < 64; j += TTN_WG) S.perm[j] = j;
                 if (tid == 0) S.scal[0] = P.jneg_mult * P.jneg_mult * 64.0 * DBL_EPSILON * DBL_EPSILON * S.sigs[0] * S.sigs[0];
                 __syncthreads();
@@ -2413,33 +2622,35 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         if (ok) {
             r = wg_rank_rule(P, S, rm, p, s0);
             rk = r < rm ? r : rm;                                           // columns that carry data
+            FINE_MARK(6)
             // X_s[:, j] = x_j * (sqrt(s0)/sA) / sigma_j^2.5 -> T1 ;  X_t[:, j] = x_j * (sqrt(s0)/sB) / sigma_j^1.5 -> T2
             const double fa = sqrt(s0) / sA, fb = sqrt(s0) / sB;
-            for (int e = tid; e < rm * rk; e += TTN_WG) {
-                const int row = e % rm, j = e / rm;
-                const double sj = S.sigs[j], xv = S.ldsX[S.perm[j] * 128 + row];
-                const double rs = sqrt(sj);
-                if (diagA) {
-                    // x_j = sigma_j w_j (w_j: left singular vector of N).  Lf = A' (D^(-1/2) w_j sqrt(s0 sigma_j) / sA),
-                    // Rf = (D^(1/2) w_j sqrt(s0) / (sB sqrt(sigma_j)))^T B'
-                    const double sd = sqrt(S.Ga[row * 129]);
-                    S.T1[j * 128 + row] = xv * (fa / (sd * rs));
-                    S.T2[j * 128 + row] = xv * sd * (fb / (sj * rs));
-                } else {
-                S.T1[j * 128 + row] = xv * (fa / (sj * sj * rs));
-                S.T2[j * 128 + row] = xv * (fb / (sj * rs));
+            if (diagA) {
+                // x_j = sigma_j w_j (w_j: left singular vector of N).  Lf = A' (D^(-1/2) w_j sqrt(s0 sigma_j) / sA),
+                // Rf = (D^(1/2) w_j sqrt(s0) / (sB sqrt(sigma_j)))^T B'
+                wg_scale_t12_diag(S.ldsX, S.sigs, S.perm, S.Ga, S.T1, S.T2, rk, fa, fb, S.Ts);
+            } else {
+                for (int e = tid; e < rm * rk; e += TTN_WG) {
+                    const int row = e % rm, j = e / rm;
+                    const double sj = S.sigs[j], xv = S.ldsX[S.perm[j] * 128 + row];
+                    const double rs = sqrt(sj);
+                    S.T1[j * 128 + row] = xv * (fa / (sj * sj * rs));
+                    S.T2[j * 128 + row] = xv * (fb / (sj * rs));
                 }
+                __syncthreads();
             }
-            __syncthreads();
             const View T1v = mkview(S.T1, plain(1), plain(128));
             const View T2v = mkview(S.T2, plain(1), plain(128));
             double* LfT = S.M;                                              // p x rk, column-major (ld = p)
             double* RfT = S.M + (long long)p * rk;                          // rk x q, row-major (ld = q)
             const View Lft = mkview(LfT, plain(1), plain(p));
             const View Rft = mkview(RfT, plain(q), plain(1));
+            FINE_MARK(7)
             if (diagA) {
-                wg_gemm(p, rk, rm, Ap, T1v, Lft, 1.0, 0.0, lds);
-                wg_gemm(rk, q, rm, tview(T2v), Bp, Rft, 1.0, 0.0, lds);
+                wg_gemm_ra(rk, p, rm, tview(T1v), tview(Ap), tview(Lft), 1.0, lds);          // Lf^T = T1^T A'^T: the short operand in registers
+                FINE_MARK(8)
+                wg_gemm_ra(rk, q, rm, tview(T2v), Bp, Rft, 1.0, lds);
+                FINE_MARK(9)
             } else {
             // Lf = A' * (L_B * (C^T * X_s))     (ldsX is free again: use it as the second temporary)
             wg_gemm(rm, rk, rm, tview(Ccv), T1v, mkview(S.T3, plain(1), plain(128)), 1.0, 0.0, lds);
@@ -2451,10 +2662,13 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             }
             // a-posteriori check: Lf^T Lf = Sigma, Rf Rf^T = Sigma
             wg_syrk(rk, p, tview(Lft), mkview(S.T1, plain(1), plain(128)), 1.0, lds);
+            FINE_MARK(10)
             wg_syrk(rk, q, Rft, mkview(S.T2, plain(1), plain(128)), 1.0, lds);
-            const double e1 = wg_check_diag(S, S.T1, 128, rk, s0);
-            const double e2 = wg_check_diag(S, S.T2, 128, rk, s0);
+            FINE_MARK(11)
+            const double e1 = wg_check_diag_tab(S.sigs, S.T1, 128, rk, s0, S.Ts, S.red);
+            const double e2 = wg_check_diag_tab(S.sigs, S.T2, 128, rk, s0, S.Ts, S.red);
             ok = (e1 <= FAST_CHECK_TOL) && (e2 <= FAST_CHECK_TOL);
+            FINE_MARK(12)
             if (ok) {
                 if (P.sv_out && step < P.sv_steps) {
                     double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
@@ -2466,7 +2680,9 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 const View Ro = wide ? Rfv : tview(Lfv);       // r x q
                 __syncthreads();
                 wg_copy_to_view(Lo, LfT, p, r, 1, p, rk, 1);               // Lo[row, j] = LfT[row + p j], columns j >= rk zero
+                FINE_MARK(13)
                 wg_copy_to_view(Ro, RfT, r, q, q, 1, rk, 0);               // Ro[j, col] = RfT[j q + col], rows j >= rk zero
+                FINE_MARK(14)
                 if (tid == 0) *io.rank_out = r;
                 __syncthreads();
                 done = true;
@@ -2546,7 +2762,8 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                     // the part it drops (the solver only computes the kept eigenvalues)
                     { double t_ = 0.0; for (int i = tid; i < p; i += TTN_WG) t_ += S.Ga[i * 129]; gram_trace = unif64(wg_sum(t_, S.red)); }
                     ok = ((p == 64) ? wg_eig64(S.Ga, 128, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64)
-                                    : wg_eig128(S.Ga, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64, nullptr)) == 0;
+                                    : wg_eig128(S.Ga, S.Gb, r0, nev, S.sigs, lds, reinterpret_cast<int*>(S.Ts), S.Ts + 64,
+                                                (P.prof && P.prof_step == step) ? P.prof + (long long)P.tt.batch * 136 + (long long)b * 64 + 32 : nullptr)) == 0;
                     for (int j = tid; j < p; j += TTN_WG) { S.perm[j] = j; if (j >= nev) S.sigs[j] = 0.0; }      // (sigs / perm hold pmax entries)
                     if (tid == 0) S.scal[0] = P.jneg_mult * P.jneg_mult * (double)p * DBL_EPSILON * DBL_EPSILON * S.sigs[0] * S.sigs[0];
                     __syncthreads();
@@ -2634,7 +2851,9 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             }
             PROF_MARK(3)
             if (!ok) continue;
+            FINE_MARK(20)
             const int r = wg_rank_rule(P, S, p, p, s0);
+            FINE_MARK(21)
             if (SWAP != 0 && r > io.cap) {                                  // would not fit the slots: report, write nothing
                 if (tid == 0) { P.status[b] = 2; *io.rank_out = -1; }
                 __syncthreads();
@@ -2673,7 +2892,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                         S.Us[(long long)j * p + row] = ((sj > 0.0) && (sj * sj > aneg0)) ? xv / sj : 0.0;
                     }
                     __syncthreads();
-                    wg_gemm(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, mkview(S.M2, plain(q), plain(1)), inv_s0, 0.0, lds);
+                    wg_gemm_ra(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, mkview(S.M2, plain(q), plain(1)), inv_s0, lds);
                     for (int e = tid; e < r * 128; e += TTN_WG) { const int c = e & 127, j = e >> 7; S.ldsX[e] = (c < q) ? S.M2[(long long)j * q + c] : 0.0; }
                     __syncthreads();
                     const int nsp = uni32(wg_svd_cols(P, S, r, S.ldsX, 128, true, q));
@@ -2718,6 +2937,9 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             const View Ro = wide ? Rfv : tview(Lfv);       // r x q
             const double sq0 = sqrt(s0);
             const double aneg = S.scal[0];
+            if (p <= 128 && r <= 128) {
+                wg_scale_image(X, ldx, (x_in_lds || attempt == 1) ? 1 : 0, S.sigs, S.perm, Lo, S.Us, p, r, s0, aneg, (SWAP == 0) ? 0 : (wide ? 1 : 2), S.Ts);
+            } else {
             for (int e = tid; e < p * r; e += TTN_WG) {
                 const int row = e % p, j = e / p;
                 const double sj = S.sigs[j];
@@ -2732,11 +2954,16 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 Lo.p[ix(Lo.r, row) + ix(Lo.c, j)] = lf;
                 S.Us[(long long)j * p + row] = us;            // Us^T stored: (r x p) row-major
             }
+            }
             __syncthreads();
-            wg_gemm(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, Ro, inv_s0, 0.0, lds);
+            FINE_MARK(22)
+            wg_gemm_ra(r, q, p, mkview(S.Us, plain(p), plain(1)), Mv, Ro, inv_s0, lds);
+            FINE_MARK(23)
             if (attempt == 1) {
                 wg_syrk(r, q, Ro, mkview(S.T2, plain(1), plain(128)), 1.0, lds);
-                const double e2 = unif64(wg_check_diag(S, S.T2, 128, r, s0));
+                FINE_MARK(24)
+                const double e2 = (r <= 128) ? wg_check_diag_tab(S.sigs, S.T2, 128, r, s0, S.Ts, S.red) : unif64(wg_check_diag(S, S.T2, 128, r, s0));
+                FINE_MARK(25)
                 if (!(e2 <= (cholqr ? CHOLQR_CHECK_TOL : FAST_CHECK_TOL))) continue;                     // redo with Householder (M is intact)
                 if (P.sv_out && step < P.sv_steps) {
                     double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
@@ -2757,6 +2984,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
     }
     __syncthreads();
 #undef PROF_MARK
+#undef FINE_MARK
 }
 
 // tt_compress! form of the step: cores k, k+1 of train b of P.tt
@@ -2991,6 +3219,7 @@ __global__ void TTN_KERNEL_BOUNDS k_selftest_gemm(int m, int n, int k, double* A
     const View Av = (ta & 1) ? mkview(A, plain(1), plain(m)) : mkview(A, plain(k), plain(1));     // ta & 1: A stored k x m
     const View Bv = tb ? mkview(B, plain(1), plain(k)) : mkview(B, plain(n), plain(1));     // tb: B stored n x k
     if (ta & 2) wg_syrk(m, k, Av, mkview(C, plain(n), plain(1)), alpha, lds);               // ta & 2: C = alpha A A^T (n == m; B, beta unused)
+    else if (ta & 4) wg_gemm_ra(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), alpha, lds);   // ta & 4: the register-A form (beta unused)
     else wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), alpha, beta, lds);
 }
 
@@ -3006,6 +3235,7 @@ __global__ void TTN_KERNEL_BOUNDS k_bench_gemm(int m, int n, int k, double* A, d
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < reps; ++r) {
         if (ta & 2) wg_syrk(m, k, Av, mkview(C, plain(n), plain(1)), 1.0, lds);            // the Gram-product routine (n == m)
+        else if (ta & 4) wg_gemm_ra(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), 1.0, lds);
         else wg_gemm(m, n, k, Av, Bv, mkview(C, plain(n), plain(1)), 1.0, 0.0, lds);
     }
     __syncthreads();

@@ -12,9 +12,10 @@ shapes = [  # (m, n, k, ta, tb, what)
     (128, 128, 64, 0, 0, "merge R->L"), (64, 64, 128, 1, 0, "gram A^T A (F)"), (64, 64, 64, 0, 0, "small 64^3"),
     (128, 128, 128, 0, 0, "128^3"), (128, 64, 128, 0, 0, "U = X W"), (192, 192, 128, 0, 0, "dot-like"),
     # ta & 2: the Gram-product routine wg_syrk (flop counted as the full 2 m m k of the GEMM it replaces)
+    (64, 384, 128, 5, 0, "ra: split Vt = U^T M"), (64, 128, 64, 5, 0, "ra: F Rf = T2^T B'"), (64, 128, 64, 4, 1, "ra: F Lf^T"),
     (128, 128, 384, 2, 0, "syrk M M^T"), (64, 64, 384, 2, 0, "syrk check / ramp"), (64, 64, 128, 2, 0, "syrk B' B'^T (F)"), (64, 64, 128, 3, 0, "syrk A'^T A' (F)"),
 ]
-if os.environ.get("TTN_DIAG_SYRK_ONLY"): shapes = [sh for sh in shapes if (sh[3] & 2) or "gram" in sh[5] or "check" in sh[5] or "B' B'^T" in sh[5]]
+if os.environ.get("TTN_DIAG_SYRK_ONLY"): shapes = [sh for sh in shapes if (sh[3] & 6) or "split" in sh[5] or "F: Lf" in sh[5] or "F: Rf" in sh[5] or "gram" in sh[5] or "check" in sh[5] or "B' B'^T" in sh[5]]
 for m, n, k, ta, tb, what in shapes:
     reps = 20
     cy = C.c_int64()

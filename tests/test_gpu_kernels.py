@@ -54,6 +54,20 @@ def test_wg_syrk_exact_on_integers(T, monkeypatch, p, q, ta, wg512):
     assert np.array_equal(got, 0.5 * (A @ A.T))
 
 
+@pytest.mark.parametrize("m,n,k", [(64, 384, 128), (64, 128, 64), (64, 96, 128), (33, 200, 70), (16, 64, 4), (64, 1088, 128), (48, 130, 127), (64, 2000, 128), (70, 100, 50)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("wg512", [0, 1])
+def test_wg_gemm_ra_exact_on_integers(T, monkeypatch, m, n, k, ta, tb, wg512):
+    """C = alpha A B by the register-A form (A fragments of all of k in registers, B streamed in column chunks), both builds; shapes
+    beyond its limits take the general GEMM."""
+    monkeypatch.setenv("TTN_WG512_SELFTEST", str(wg512))
+    rng = np.random.default_rng(m * 1000 + n * 10 + k)
+    A = rng.integers(-8, 9, size=(m, k)).astype(np.float64)
+    B = rng.integers(-8, 9, size=(k, n)).astype(np.float64)
+    got = _gemm(T, A.T if ta else A, B.T if tb else B, np.full((m, n), np.nan), -1.5, 0.0, 4 | ta, tb)
+    assert np.array_equal(got, -1.5 * (A @ B))
+
+
 def test_wg_gemm_random_fp64(T):
     rng = np.random.default_rng(5)
     A = rng.standard_normal((128, 192))
