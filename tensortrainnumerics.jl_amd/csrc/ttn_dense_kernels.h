@@ -1890,7 +1890,8 @@ struct CompressArgs {
     int fast;              // 0: Householder route only; odd: try the Gram / factored fast paths (verified a posteriori) first.
                            // Diagnostic bits (TTN_FAST): 2 no eigensolver in route G (Cholesky + Jacobi), 4 none in route F,
                            // 8 no diagonal-left shortcut in route F, 16 no Jacobi polish after a failed conditioning test, 32 no CholeskyQR2,
-                           // 64 Gram / reflector / check matrices in their own scratch instead of the dead T buffer
+                           // 64 Gram / reflector / check matrices in their own scratch instead of the dead T buffer, 128 two-pass fused merge,
+                           // 512 no barrier-free (direct) form of the one-pass merge
     // fused apply (ttn_apply_compress): psi = A * x is never materialised.  During the FIRST L->R sweep core k+1 of psi
     // is still virtual (= A_{k+1} applied to x_{k+1}); psi's ranks already hold A.rks .* x.rks.
     int fused;
@@ -2373,9 +2374,183 @@ __device__ __noinline__ bool wg_fused_merge_mfma(double* ck, const double* xc, c
     return true;
 }
 
+// ---- the one-pass merge without barriers in its main loop ("direct" form) ------------------------------------------------------------
+// wg_fused_merge_mfma stages chunks of FM_BK = 8 values of nu' of BOTH operands through LDS: 8 chunks x 4 column passes = 32 barrier
+// rounds of 12 MFMAs per wave each for a 128-row step — the barriers and the staging, not the matrix pipe, set its time (29 % of the
+// pipe alone, 18 % with two workgroups per CU).  Here the x core (rho_l x n2 rho_r, 64 KB for rank 64) is staged ONCE, whole, and the
+// A fragments — lane (li, lk) needs C_k[row 16 rt + li, a' + Rl (4 ks + lk)] — are loaded from global memory (L2) straight into the
+// MFMA operand registers, four k-steps ahead of their use: no LDS staging of C_k, no barrier between the staging of x and the epilogue.
+// Same tiling (a wave = one 16-row tile x two 16-column tiles x Rl accumulators), same epilogue.
+__device__ __noinline__ bool wg_fused_merge_direct(double* ck, const double* xc, const double* ac, double* M, int p, int q, int n1, int Dl,
+                                                   int rhl, int rhr, int Rl, int Rr, double* lds, double* amax_lds, double* red, long long* stamps) {
+    stamps = unip(stamps);
+#define FMD_STAMP(i) if (stamps && threadIdx.x == 0) stamps[i] = (long long)__builtin_amdgcn_s_memtime();
+    FMD_STAMP(0)
+    ck = unip(ck); xc = unip(xc); ac = unip(ac); M = unip(M); lds = unip(lds); amax_lds = unip(amax_lds); red = unip(red);
+    p = uni32(p); q = uni32(q); n1 = uni32(n1); Dl = uni32(Dl); rhl = uni32(rhl); rhr = uni32(rhr); Rl = uni32(Rl); Rr = uni32(Rr);
+    constexpr int n2 = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int RT = p >> 4;
+    const int WR = RT < 8 ? RT : 8;
+    const int WC = TTN_NWAVES / WR;
+    const int CP = 32 * WC;
+    const int ncol = n2 * rhr, nin = Rl * n2, nout = n2 * Rr;
+    const int LDB = ncol + 1;                                        // odd: the four k rows of a fragment read land two banks apart
+    if (Rl < 1 || Rl > 3 || Rr > 4 || (p & 15) || (rhl & 15) || (ncol % CP) || (RT % WR) || WR * WC != TTN_NWAVES ||
+        (long long)rhl * LDB + 64 > GEMM_LDS_DOUBLES)
+        return false;
+    lds_f64* Bs = (lds_f64*)lds;                                     // Bs[kk * LDB + col], kk = nu' < rho_l, col = j + n2 nu
+    lds_f64* opl = Bs + rhl * LDB;                                   // operator core: opl[o * nin + i], o = s + n2 a, i = j + n2 a'
+    gmem_f64* Cg = (gmem_f64*)ck;
+    gmem_f64* Xg = (gmem_f64*)xc;
+    gmem_wf64* Mg = (gmem_wf64*)M;
+    __syncthreads();
+    for (int e = tid; e < nin * nout; e += TTN_WG) {
+        const int i = e % nin, o = e / nin;
+        opl[e] = ac[(o % n2) + n2 * ((i % n2) + n2 * ((i / n2) + (long long)Rl * (o / n2)))];
+    }
+    // x[j, nu', nu] at j + n2 (nu' + rho_l nu): consecutive threads walk (j, nu') of one nu — contiguous in memory
+    {
+        const int nx = rhl * ncol, kspan = n2 * rhl;                 // elements of one nu
+        for (int e0 = tid; e0 < nx; e0 += 8 * TTN_WG) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + u * TTN_WG; v[u] = Xg[e < nx ? e : e0]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * TTN_WG;
+                if (e < nx) { const int nu = e / kspan, w_ = e - nu * kspan, j = w_ & 1, kk = w_ >> 1; Bs[kk * LDB + j + n2 * nu] = v[u]; }
+            }
+        }
+    }
+    __syncthreads();
+    FMD_STAMP(1)
+    const long long ldk = (long long)n1 * Dl;                        // column stride of C_k as a (n1 Dl) x (Rl rho_l) matrix
+    const int wr = wave % WR, wc = wave / WR;
+    const int ksteps = rhl >> 2, ngrp = ksteps >> 2;                 // groups of four k-steps
+    const int kstride = (int)(ldk * Rl);                             // address advance per nu'
+    double cmax = 0.0;
+    const int jl = li & 1;
+    for (int rb = 0; rb < RT; rb += WR) {
+        const int arow = 16 * (rb + wr) + li;
+        // C_k[(al, s1), ga] at s1 + n1 (al + Dl ga), row = al + Dl s1, ga = a' + Rl nu'
+        const int abase = (arow % Dl) * n1 + arow / Dl + lk * kstride;
+        for (int c0 = 0; c0 < ncol; c0 += CP) {
+            mfma_acc_t acc[3][2];
+#pragma unroll
+            for (int a1 = 0; a1 < 3; ++a1) { acc[a1][0] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0}; acc[a1][1] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0}; }
+            double cur[4][3], nxt[4][3];
+#define FMD_LOAD(DST, G)                                                                                                \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                \
+                _Pragma("unroll") for (int a1 = 0; a1 < 3; ++a1)                                                         \
+                    DST[t][a1] = (a1 < Rl) ? Cg[abase + (4 * (4 * (G) + t)) * kstride + a1 * (int)ldk] : 0.0;
+            FMD_LOAD(cur, 0)
+            const lds_f64* bcol = Bs + lk * LDB + c0 + wc * 32 + li;
+            for (int g = 0; g < ngrp; ++g) {
+                if (g + 1 < ngrp) { FMD_LOAD(nxt, g + 1) }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kr = 4 * (4 * g + t);
+                    const double b0 = bcol[kr * LDB], b1 = bcol[kr * LDB + 16];
+#pragma unroll
+                    for (int a1 = 0; a1 < 3; ++a1) {
+                        if (a1 < Rl) {
+                            acc[a1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[t][a1], b0, acc[a1][0], 0, 0, 0);
+                            acc[a1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[t][a1], b1, acc[a1][1], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int a1 = 0; a1 < 3; ++a1) cur[t][a1] = nxt[t][a1];
+            }
+#undef FMD_LOAD
+            if (rb == 0 && c0 == 0) { FMD_STAMP(2) }
+            // ---- epilogue: lane (li, lk) holds T_a'[row = lk + 4 reg][column li] of its two column tiles; column = j + n2 nu.
+            // Both lanes of a (j = 0, 1) pair end up with all nout sums of their (row, nu); the pair then writes the nout consecutive
+            // doubles M[row, nout nu ...] as two contiguous halves (lane j = 0 the first nout / 2, lane j = 1 the rest), 16 bytes at a
+            // time where the address allows: the 16 lanes of a row of lanes cover 8 nu = 8 nout contiguous doubles of one row of M —
+            // whole cache lines per store instruction.  (Stored one output at a time, lanes 6 doubles apart and half of them idle,
+            // these stores, not the MFMAs, set the time of the merge.) ----
+            const int half = nout >> 1;
+            const bool vec_ok = (half == 3) && ((((unsigned long long)Mg) & 15ull) == 0) && ((q & 1) == 0);
+            if (vec_ok && Rl == 3) {
+                // Operator ranks 3 x 3 (the Laplacian's interior cores): the pair first swaps its raw T values (one DPP move per a'), then
+                // each lane forms ITS three outputs from all six inputs — weights w[oo][a'][own / other j] read from LDS once per pass —
+                // and stores them as 16 + 8 bytes.
+                double w[3][3][2];
+#pragma unroll
+                for (int oo = 0; oo < 3; ++oo)
+#pragma unroll
+                    for (int a1 = 0; a1 < 3; ++a1) {
+                        const int o = 3 * jl + oo;
+                        w[oo][a1][0] = opl[o * nin + jl + n2 * a1];          // own j
+                        w[oo][a1][1] = opl[o * nin + (1 - jl) + n2 * a1];    // the neighbour's j
+                    }
+                typedef double dbl2 __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(1))) dbl2 gmem_wd2;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int nu = (c0 + wc * 32 + ct * 16 + li) >> 1;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int row = 16 * (rb + wr) + lk + 4 * reg;
+                        gmem_wf64* mrow = Mg + ((long long)row * q + (long long)nout * nu);
+                        const double t0 = acc[0][ct][reg], t1 = acc[1][ct][reg], t2 = acc[2][ct][reg];
+                        const double u0 = dpp_mov_f64<0xB1>(t0), u1 = dpp_mov_f64<0xB1>(t1), u2 = dpp_mov_f64<0xB1>(t2);      // quad_perm [1,0,3,2]
+                        double v[3];
+#pragma unroll
+                        for (int oo = 0; oo < 3; ++oo) {
+                            double x_ = t0 * w[oo][0][0];
+                            x_ = fma(u0, w[oo][0][1], x_);
+                            x_ = fma(t1, w[oo][1][0], x_); x_ = fma(u1, w[oo][1][1], x_);
+                            x_ = fma(t2, w[oo][2][0], x_); x_ = fma(u2, w[oo][2][1], x_);
+                            v[oo] = x_;
+                            cmax = fmax(cmax, fabs(x_));
+                        }
+                        // j = 0: (o0, o1) as 16 bytes at +0, o2 at +2;  j = 1: o3 at +3, (o4, o5) as 16 bytes at +4
+                        *(gmem_wd2*)(mrow + (jl ? 4 : 0)) = jl ? (dbl2){v[1], v[2]} : (dbl2){v[0], v[1]};
+                        mrow[jl ? 3 : 2] = jl ? v[0] : v[2];
+                    }
+                }
+            } else {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int nu = (c0 + wc * 32 + ct * 16 + li) >> 1;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 16 * (rb + wr) + lk + 4 * reg;
+                    gmem_wf64* mrow = Mg + ((long long)row * q + (long long)nout * nu);
+                    for (int o = 0; o < nout; ++o) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int a1 = 0; a1 < 3; ++a1)
+                            if (a1 < Rl) v = fma(acc[a1][ct][reg], opl[o * nin + jl + n2 * a1], v);
+                        v += dpp_mov_f64<0xB1>(v);                   // + the other j (quad_perm [1,0,3,2]): both lanes of the pair hold the sum
+                        if ((o >= half) == (jl == 1)) mrow[o] = v;   // the pair shares the stores: each lane a contiguous half
+                        cmax = fmax(cmax, fabs(v));
+                    }
+                }
+            }
+            }
+            if (rb == 0 && c0 == 0) { FMD_STAMP(3) }
+        }
+    }
+    FMD_STAMP(4)
+    cmax = wg_max(cmax, red);
+    if (tid == 0) *amax_lds = cmax;
+    __syncthreads();
+    FMD_STAMP(5)
+#undef FMD_STAMP
+    return true;
+}
+
+
 #define FUSE_MAX_TERMS 16
 __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q, const View& Am, double* M, double* Tbuf,
-                               long long tbuf_doubles, double* lds, double* amax_lds, double* red) {
+                               long long tbuf_doubles, double* lds, double* amax_lds, double* red, long long* stamps = nullptr) {
     const TTDev& T = P.tt;
     const int n1 = T.dims[k], n2 = T.dims[k + 1];
     const long long* rks = T.rks + (long long)b * (T.d + 1);
@@ -2389,6 +2564,7 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
     double* ck = T.data + (long long)b * T.stride + T.off[k];
     double* xc = P.x.data + (long long)b * P.x.stride + P.x.off[k + 1];
     const double* ac = P.op.data + P.op.off[k + 1];
+    if (n2 == 2 && !(P.fast & 128) && !(P.fast & 512) && wg_fused_merge_direct(ck, xc, ac, M, p, q, n1, Dl, rhl, rhr, Rl, Rr, lds, amax_lds, red, stamps)) return true;
     if (n2 == 2 && !(P.fast & 128) && wg_fused_merge_mfma(ck, xc, ac, M, p, q, n1, Dl, rhl, rhr, Rl, Rr, lds, amax_lds, red)) return true;
     const long long ldk = (long long)n1 * Dl;                           // column stride of C_k viewed as (n1*Dl) x r_mid
     for (int a1 = 0; a1 < Rl; ++a1) {
@@ -2699,7 +2875,10 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         // apply 1/s0 as their alpha — no extra read-modify-write pass over the p x q matrix.
         bool merged = false;
         if (virt_live) {
-            merged = wg_fused_merge(P, b, k, p, q, Am, S.M, S.M2, pq, lds, S.scal + 6, S.red);
+            FINE_MARK(26)
+            merged = wg_fused_merge(P, b, k, p, q, Am, S.M, S.M2, pq, lds, S.scal + 6, S.red,
+                                    (P.prof && P.prof_step == step) ? P.prof + (long long)P.tt.batch * 136 + (long long)b * 64 + 48 : nullptr);
+            FINE_MARK(27)
             if (!merged) wg_materialize_core(P, b, k + 1);
         }
         double mx_swap = 0.0;

@@ -26,7 +26,7 @@ for tb in range(min(B, 64)):
 med = np.median(np.array(rows, dtype=np.float64), axis=0)
 F = ["absmax x2", "syrk A'^T A'", "syrk B' B'^T", "diag test", "T3 = D^1/2 Gb D^1/2", "eig64", "kappa test + rank rule", "T1/T2 scaling", "Lf^T GEMM", "Rf GEMM",
      "check syrk Lf", "check syrk Rf", "check_diag x2", "copy Lf -> core", "copy Rf -> core"]
-G = {20: "(merge, Gram, eig ... up to the rank rule)", 21: "rank rule", 22: "kept-block test + Us scaling", 23: "Ro = Us^T M GEMM", 24: "check syrk Ro", 25: "check_diag"}
+G = {26: "step prologue (before the merge)", 27: "fused merge (whole call)", 20: "(merge, Gram, eig ... up to the rank rule)", 21: "rank rule", 22: "kept-block test + Us scaling", 23: "Ro = Us^T M GEMM", 24: "check syrk Ro", 25: "check_diag"}
 print(f"step {os.environ.get('TTN_PROF_STEP')}  batch {B}  build {'512' if os.environ.get('TTN_WG512') == '1' or (B > 256 and os.environ.get('TTN_WG512') != '0') else '1024'}: median ticks over {len(rows)} trains")
 for i, nme in enumerate(F):
     if med[i] > 0: print(f"  F {i:2d} {nme:28s} {med[i]:10.0f}")
@@ -38,3 +38,8 @@ if e[2] > 0:
     ks = [k for k in range(2, 12) if e[k] > 0]
     for a, b_ in zip(ks[:-1], ks[1:]):
         print(f"  eig mark {a}->{b_} {e[b_] - e[a]:10.0f}")
+
+m = med[48:56]
+if m[5] > 0:
+    for a, b_, nme in [(0, 1, "operator core + x staging + barrier"), (1, 2, "first pass: main loop (A loads + MFMAs)"), (2, 3, "first pass: epilogue"), (3, 4, "remaining passes"), (4, 5, "max reduction + barrier")]:
+        print(f"  merge {nme:42s} {m[b_] - m[a]:10.0f}")
