@@ -17,6 +17,21 @@
 #else
 #define TTN_KERNEL_BOUNDS __launch_bounds__(TTN_WG)
 #endif
+// Wave priorities of the dense kernels (s_setprio; see ttn_dense_kernels.h): matrix-product routines 0, everything else
+// TTN_PRIO_BASE, the symmetric eigensolver TTN_EIG_PRIO, the one wave that carries the tridiagonalisation's serial chain
+// TTN_TRIDIAG_PRIO.  Only the order matters (3/3/2 and 3/3/1 measure the same).  -DTTN_NO_PRIO builds without them: 556 k instead of
+// 583 k cores/s on the benchmark (same box), no difference for one train alone on a CU.
+#ifndef TTN_NO_PRIO
+#ifndef TTN_PRIO_BASE
+#define TTN_PRIO_BASE 1
+#endif
+#ifndef TTN_EIG_PRIO
+#define TTN_EIG_PRIO 2
+#endif
+#ifndef TTN_TRIDIAG_PRIO
+#define TTN_TRIDIAG_PRIO 3
+#endif
+#endif
 #define TTN_MAX_D 64           // max chain length handled by the on-stack tables of the host API
 #define TTN_SV_NONE (-1)
 

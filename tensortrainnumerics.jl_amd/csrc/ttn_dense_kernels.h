@@ -30,6 +30,17 @@
 #include <float.h>
 
 #define GEMM_BK 16
+// Wave priorities (s_setprio, a per-wave hint to the SIMD's issue arbiter): with two workgroups per CU one of them is usually in a
+// latency-bound phase (an eigensolver's serial chain, a Cholesky pivot, a Jacobi sweep) while the other streams MFMAs; the
+// latency-bound waves issue first.  Levels: TTN_PRIO_BASE for everything that is not a matrix product, 0 inside the matrix-product
+// routines, higher inside the eigensolver (ttn_eig_kernels.h).
+#ifdef TTN_PRIO_BASE
+#define TTN_SETPRIO_GEMM() __builtin_amdgcn_s_setprio(0)
+#define TTN_SETPRIO_BASE() __builtin_amdgcn_s_setprio(TTN_PRIO_BASE)
+#else
+#define TTN_SETPRIO_GEMM()
+#define TTN_SETPRIO_BASE()
+#endif
 // LDS leading dimension (doubles) of the staged chunks, 145 = 17 mod 32.  Two access patterns meet here:
 //  * a k-fast operand is staged by 16 lanes that walk k (coalesced global reads) and store to As[kk*LD + r]: an even LD
 //    puts all 16 stores on ONE bank pair (16-way conflict: measured 49 % of the MFMA peak with LD = 144, stores alone
@@ -570,6 +581,7 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
         if (amax_lds) *amax_lds = 0.0;
     }
     __syncthreads();
+    TTN_SETPRIO_GEMM();
     const bool shape_ok = (m <= 128) && (n <= 128) && (((m + 15) >> 4) * ((n + 15) >> 4) <= 32);
     const int wpad = small_ld(m) + small_ld(n), wtight = tight_ld(m) + tight_ld(n);
     if (shape_ok && (long long)k * wpad <= GEMM_LDS_DOUBLES) {
@@ -602,6 +614,7 @@ __device__ inline void wg_gemm(int m, int n, int k, View A, View B, View C, doub
     } else {
         wg_gemm_impl<4>(dsc, lds);
     }
+    TTN_SETPRIO_BASE();
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -707,6 +720,7 @@ __device__ inline void wg_syrk(int p, int q, View A, View G, double alpha, doubl
     __syncthreads();                         // nobody still reads what the tiles / descriptor alias
     if (threadIdx.x == 0) { dsc->m = p; dsc->n = p; dsc->k = q; dsc->pad = 0; dsc->A = A; dsc->C = G; dsc->alpha = alpha; dsc->beta = 0.0; dsc->amax = nullptr; }
     __syncthreads();
+    TTN_SETPRIO_GEMM();
 #if TTN_WG == 512
     if (p > 64) wg_syrk_impl<3, 4, 5>(dsc, lds);         // 128 rows: chunks of 48 k (145 x 48 doubles), 36 tiles on 8 waves
     else wg_syrk_impl<6, 2, 2>(dsc, lds);                // <= 64 rows: chunks of 96 k (81 x 96), 10 tiles
@@ -714,6 +728,7 @@ __device__ inline void wg_syrk(int p, int q, View A, View G, double alpha, doubl
     if (p > 64) wg_syrk_impl<6, 2, 3>(dsc, lds);         // 145 x 96 doubles, 36 tiles on 16 waves
     else wg_syrk_impl<6, 1, 1>(dsc, lds);
 #endif
+    TTN_SETPRIO_BASE();
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -810,7 +825,9 @@ __device__ inline void wg_gemm_ra(int m, int n, int k, View A, View B, View C, d
     __syncthreads();
     if (threadIdx.x == 0) { dsc->m = m; dsc->n = n; dsc->k = k; dsc->pad = 0; dsc->A = A; dsc->B = B; dsc->C = C; dsc->alpha = alpha; dsc->beta = 0.0; dsc->amax = nullptr; }
     __syncthreads();
+    TTN_SETPRIO_GEMM();
     wg_gemm_ra_impl(dsc, lds);
+    TTN_SETPRIO_BASE();
 #endif
 }
 
@@ -2564,6 +2581,8 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
     double* ck = T.data + (long long)b * T.stride + T.off[k];
     double* xc = P.x.data + (long long)b * P.x.stride + P.x.off[k + 1];
     const double* ac = P.op.data + P.op.off[k + 1];
+    TTN_SETPRIO_GEMM();
+    struct PrioRestore { __device__ ~PrioRestore() { TTN_SETPRIO_BASE(); } } prio_restore_;
     if (n2 == 2 && !(P.fast & 128) && !(P.fast & 512) && wg_fused_merge_direct(ck, xc, ac, M, p, q, n1, Dl, rhl, rhr, Rl, Rr, lds, amax_lds, red, stamps)) return true;
     if (n2 == 2 && !(P.fast & 128) && wg_fused_merge_mfma(ck, xc, ac, M, p, q, n1, Dl, rhl, rhr, Rl, Rr, lds, amax_lds, red)) return true;
     const long long ldk = (long long)n1 * Dl;                           // column stride of C_k viewed as (n1*Dl) x r_mid
@@ -3183,6 +3202,7 @@ __device__ __forceinline__ void wg_bond_step(const CompressArgs& P, int b, int k
 }
 
 __global__ void TTN_KERNEL_BOUNDS k_compress(CompressArgs P) {
+    TTN_SETPRIO_BASE();
     extern __shared__ double lds[];
     const int d = P.tt.d;
     // ONE call site of the (force-inlined) bond step: as an out-of-line function it received its arguments in VGPRs, so

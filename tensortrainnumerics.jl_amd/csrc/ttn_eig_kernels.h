@@ -137,6 +137,9 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
         lds_barrier();
         double v0 = 0.0, v1 = 0.0, w0 = 0.0, w1 = 0.0;
         if (wave == 0) {
+#ifdef TTN_TRIDIAG_PRIO
+            __builtin_amdgcn_s_setprio(TTN_TRIDIAG_PRIO);          // the serial chain of the column ahead of everybody's parallel work
+#endif
             const double bta = beta[k];
             v0 = vL[lane]; v1 = TWO ? vL[lane + 64] : 0.0;
             double p0 = 0.0, p1 = 0.0;
@@ -163,6 +166,13 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
             const double xk1 = (kk + 1 < 64) ? readlane_f64(c0, kk + 1) : readlane_f64(c1, kk + 1 - 64);
             const double x0 = (lane > kk) ? c0 : 0.0, x1 = (TWO && lane + 64 > kk) ? c1 : 0.0;
             tridiag_reflector(kk, x0, x1, xk1, lane, vN, Vst, dg, e, beta, dgk);
+#ifdef TTN_TRIDIAG_PRIO
+#ifdef TTN_EIG_PRIO
+            __builtin_amdgcn_s_setprio(TTN_EIG_PRIO);
+#else
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
         }
         if (live) {
             // A -= v w' + w v'
@@ -447,6 +457,9 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define EIG_MARK(slot) if (prof && threadIdx.x == 0) prof[slot] = (long long)__builtin_amdgcn_s_memtime();
     EIG_MARK(2)
+#ifdef TTN_EIG_PRIO
+    __builtin_amdgcn_s_setprio(TTN_EIG_PRIO);                  // the whole solver is latency bound: ahead of a co-resident workgroup's GEMM phases
+#endif
     wg_tridiag<N>(Gg, ldg, Vst, lds);
     EIG_MARK(3)
     // lanes per eigenvalue: the Sturm loop is issue bound, so the optimum is ONE busy wave per SIMD (4 waves) — 4 lanes for the
@@ -457,7 +470,12 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
     // eigenvalues out; those whose vectors are wanted must be positive (the others are only reported: 0 if not positive)
     int bad = 0;
     for (int j = tid; j < nev; j += TTN_WG) { const double l = lam[j]; sig[j] = (l > 0.0) ? sqrt(l) : 0.0; bad |= (j < r) && !(l > 0.0); }
-    if (__syncthreads_or(bad)) return 1;
+    if (__syncthreads_or(bad)) {
+#ifdef TTN_EIG_PRIO
+        __builtin_amdgcn_s_setprio(0); TTN_SETPRIO_BASE();
+#endif
+        return 1;
+    }
     EIG_MARK(4)
     wg_twisted<N>(r, lds, iwork, (lds_f64*)dwork, const_cast<double*>(Gg));
     EIG_MARK(5)
@@ -522,6 +540,9 @@ __device__ __noinline__ int wg_eig_n(const double* Gg, int ldg, double* Vst, int
         }
     }
     __syncthreads();
+#ifdef TTN_EIG_PRIO
+    __builtin_amdgcn_s_setprio(0); TTN_SETPRIO_BASE();
+#endif
     return 0;
 #undef EIG_MARK
 }
