@@ -1908,7 +1908,7 @@ struct CompressArgs {
                            // Diagnostic bits (TTN_FAST): 2 no eigensolver in route G (Cholesky + Jacobi), 4 none in route F,
                            // 8 no diagonal-left shortcut in route F, 16 no Jacobi polish after a failed conditioning test, 32 no CholeskyQR2,
                            // 64 Gram / reflector / check matrices in their own scratch instead of the dead T buffer, 128 two-pass fused merge,
-                           // 512 no barrier-free (direct) form of the one-pass merge
+                           // 512 no barrier-free (direct) form of the one-pass merge, 1024 no LDS-only path for the tiny steps
     // fused apply (ttn_apply_compress): psi = A * x is never materialised.  During the FIRST L->R sweep core k+1 of psi
     // is still virtual (= A_{k+1} applied to x_{k+1}); psi's ranks already hold A.rks .* x.rks.
     int fused;
@@ -2627,6 +2627,142 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
     return true;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Bond steps with a SHORT side of at most 8 rows (the first and last three steps of each half sweep: p = 2, 4, 8, q <= 256; with
+// 12..16 rows the row-wise Jacobi below loses to LQ + Jacobi on the triangle: measured).
+// Through the general machinery — GEMM calls, Householder LQ, Jacobi image, output GEMM, each with its descriptor, barriers and
+// global round trips — such a step costs 80..300 k clk, almost all of it fixed overhead (a 2 x 24 matrix: 154 k clk; twenty of them
+// are 5 % of a train alone on a CU).  Here the merged matrix lives in LDS from the product to the outputs:
+//   M = A' B' by one thread per entry;  one-sided Jacobi on the ROWS of M (one wave per pair, round-robin rounds; no LQ first:
+//   the rows are at most 256 long) with the same rotations applied to a p x p identity — rows of the result are sigma_i v_i^T, the
+//   rotated identity is U^T;  sort, rank rule, and U sqrt(S) / sqrt(S) V^T are written straight from LDS.
+// Same conventions as the Householder route: units of s0 = max |M|, negligible rows (norm^2 <= aneg) are left alone and come out as
+// exact zeros, convergence when a whole sweep rotates nothing (|g| <= tol sqrt(a b), tol = jtol_mult sqrt(q) eps).
+// -------------------------------------------------------------------------------------------------
+#define SMALL_STEP_PMAX 8
+#define SMALL_STEP_QMAX 256
+__device__ __noinline__ int wg_bond_small(const CompressArgs& P, const BondCtx& S, int b, int step, View Ap, View Bp, int p, int q, int rm,
+                                          double* ck, double* ck1, int n1, int n2, int Dl, int wide, long long* rank_out, double* lds) {
+    p = uni32(p); q = uni32(q); rm = uni32(rm); b = uni32(b); step = uni32(step); n1 = uni32(n1); n2 = uni32(n2); Dl = uni32(Dl); wide = uni32(wide);
+    Ap = uniView(Ap); Bp = uniView(Bp); ck = unip(ck); ck1 = unip(ck1); rank_out = unip(rank_out); lds = unip(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LDQ = q + 1;
+    lds_f64* Ms = (lds_f64*)lds;                                   // Ms[i * LDQ + j]
+    lds_f64* Es = Ms + SMALL_STEP_PMAX * (SMALL_STEP_QMAX + 1);    // Es[i * 17 + j]: the rotated identity (row i = U[:, i]^T)
+    lds_f64* nr = Es + SMALL_STEP_PMAX * 17;                       // squared row norms (16)
+    lds_i32* flg = (lds_i32*)(nr + 16);
+    gmem_f64* Ag = (gmem_f64*)Ap.p;
+    gmem_f64* Bg = (gmem_f64*)Bp.p;
+    __syncthreads();
+    // ---- M = A' B' (p x q, inner rm), max |M| ----
+    double mx = 0.0;
+    for (int e = tid; e < p * q; e += TTN_WG) {
+        const int i = e / q, j = e - i * q;
+        const long long ao = ix(Ap.r, i), bo = ix(Bp.c, j);
+        double acc = 0.0;
+        for (int kk = 0; kk < rm; ++kk) acc = fma(Ag[ao + ix(Ap.c, kk)], Bg[bo + ix(Bp.r, kk)], acc);
+        Ms[i * LDQ + j] = acc;
+        mx = fmax(mx, fabs(acc));
+    }
+    for (int e = tid; e < p * 17; e += TTN_WG) Es[e] = ((e / 17) == (e % 17)) ? 1.0 : 0.0;
+    mx = unif64(wg_max(mx, S.red));
+    const double s0 = (mx > 0.0) ? mx : 1.0, inv_s0 = 1.0 / s0;
+    for (int e = tid; e < p * q; e += TTN_WG) { const int i = e / q, j = e - i * q; Ms[i * LDQ + j] *= inv_s0; }
+    __syncthreads();
+    // ---- squared row norms, negligible threshold ----
+    double amax = 0.0;
+    for (int i = wave; i < p; i += TTN_NWAVES) {
+        double a = 0.0;
+        for (int j = lane; j < q; j += 64) { const double v = Ms[i * LDQ + j]; a = fma(v, v, a); }
+        a = wave_sum(a);
+        if (lane == 0) nr[i] = a;
+        amax = fmax(amax, a);
+    }
+    amax = unif64(wg_max(amax, S.red));
+    const double aneg = P.jneg_mult * P.jneg_mult * (double)q * DBL_EPSILON * DBL_EPSILON * amax;
+    const double tol = P.jtol_mult * sqrt((double)q) * DBL_EPSILON;
+    if (tid == 0) S.scal[0] = aneg;
+    // ---- one-sided Jacobi on the rows ----
+    const int pe = p + (p & 1), half = pe >> 1;
+    int sweeps = 0, conv = (p < 2);
+    for (; !conv && sweeps < JACOBI_MAX_SWEEPS; ++sweeps) {
+        if (tid == 0) *flg = 0;
+        __syncthreads();
+        int rotated = 0;
+        for (int round = 0; round < pe - 1; ++round) {
+            for (int kk = wave; kk < half; kk += TTN_NWAVES) {
+                int i, j;
+                if (kk == 0) { i = round; j = pe - 1; }
+                else { i = (round + kk) % (pe - 1); j = (round + pe - 1 - kk) % (pe - 1); }
+                if (i > j) { const int t = i; i = j; j = t; }
+                if (j >= p) continue;                                  // bye
+                lds_f64* xi = Ms + i * LDQ;
+                lds_f64* xj = Ms + j * LDQ;
+                double a = 0.0, b_ = 0.0, g = 0.0;
+                for (int c = lane; c < q; c += 64) { const double u = xi[c], v = xj[c]; a = fma(u, u, a); b_ = fma(v, v, b_); g = fma(u, v, g); }
+                a = wave_sum(a); b_ = wave_sum(b_); g = wave_sum(g);
+                if (a <= aneg || b_ <= aneg) continue;
+                if (fabs(g) <= tol * sqrt(a) * sqrt(b_)) continue;
+                const double zeta = (b_ - a) / (2.0 * g);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+                const double cs = 1.0 / sqrt(fma(t, t, 1.0)), sn = cs * t;
+                for (int c = lane; c < q; c += 64) { const double u = xi[c], v = xj[c]; xi[c] = cs * u - sn * v; xj[c] = sn * u + cs * v; }
+                if (lane < p) { const double u = Es[i * 17 + lane], v = Es[j * 17 + lane]; Es[i * 17 + lane] = cs * u - sn * v; Es[j * 17 + lane] = sn * u + cs * v; }
+                rotated = 1;
+            }
+            __syncthreads();
+        }
+        if (rotated && lane == 0) atomicOr((int*)flg, 1);
+        __syncthreads();
+        conv = !(*flg);
+        __syncthreads();
+    }
+    // ---- sigma_i = ||row i||, sorted descending (stable) ----
+    for (int i = wave; i < p; i += TTN_NWAVES) {
+        double a = 0.0;
+        for (int j = lane; j < q; j += 64) { const double v = Ms[i * LDQ + j]; a = fma(v, v, a); }
+        a = wave_sum(a);
+        if (lane == 0) nr[i] = sqrt(a);
+    }
+    __syncthreads();
+    for (int c = tid; c < p; c += TTN_WG) {
+        const double sc = nr[c];
+        int pos = 0;
+        for (int j = 0; j < p; ++j) { const double sj = nr[j]; pos += (sj > sc) || (sj == sc && j < c); }
+        S.perm[pos] = c;
+        S.sigs[pos] = sc;
+    }
+    __syncthreads();
+    const int r = wg_rank_rule(P, S, p, p, s0);
+    if (P.sv_out && step < P.sv_steps) {
+        double* so = P.sv_out + ((long long)b * P.sv_steps + step) * P.pmax;
+        for (int i = tid; i < P.pmax; i += TTN_WG) so[i] = (i < p) ? S.sigs[i] * s0 : -1.0;
+    }
+    // ---- outputs: left factor (p x r) = U sqrt(s0 Sigma), right factor (r x q) = sqrt(s0 / Sigma) (sigma v^T) ----
+    const View Lfv = mkview(ck, Idx{Dl, (long long)n1, 1}, plain((long long)n1 * Dl));
+    const View Rfv = mkview(ck1, plain(n2), Idx{n2, 1, (long long)n2 * r});
+    const View Lo = wide ? Lfv : tview(Rfv);
+    const View Ro = wide ? Rfv : tview(Lfv);
+    const double sq0 = sqrt(s0);
+    for (int e = tid; e < p * r; e += TTN_WG) {
+        const int row = e % p, j = e / p;
+        const double sj = S.sigs[j];
+        const int pj = S.perm[j];
+        const bool keep = (sj > 0.0) && (sj * sj > aneg);
+        Lo.p[ix(Lo.r, row) + ix(Lo.c, j)] = keep ? Es[pj * 17 + row] * (sq0 * sqrt(sj)) : 0.0;
+    }
+    for (int e = tid; e < r * q; e += TTN_WG) {
+        const int col = e % q, j = e / q;
+        const double sj = S.sigs[j];
+        const int pj = S.perm[j];
+        const bool keep = (sj > 0.0) && (sj * sj > aneg);
+        Ro.p[ix(Ro.r, j) + ix(Ro.c, col)] = keep ? Ms[pj * LDQ + col] * (sq0 / sqrt(sj)) : 0.0;
+    }
+    if (tid == 0) { *rank_out = r; if (!conv) P.status[b] = 1; }
+    __syncthreads();
+    return sweeps;
+}
+
 // One bond step on (core_k, core_{k+1}), 0-based k.  src/tt_tools.jl:743-768 with the effective
 // _svdtrunc of src/tt_cross_interpolation.jl:149-166.
 //
@@ -2701,6 +2837,22 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         // the Gram matrix, the reflector store and the check matrix take the place of the fused merge's T buffer / the LQ copy
         // (dead by the time they are written): 288 KB less footprint per train, and the lines are warm
         S.Ga = S.M2; S.Gb = S.M2 + 128 * 128; S.T2 = S.M2 + 2 * 128 * 128;
+    }
+
+    // tiny steps (short side <= 8): everything in LDS, no GEMM / LQ / image machinery (wg_bond_small)
+    if (SWAP == 0 && P.fast && !(P.fast & 1024) && p >= 2 && p <= SMALL_STEP_PMAX && q <= SMALL_STEP_QMAX && P.pmax >= p) {
+        if (virt) wg_materialize_core(P, b, k + 1);
+        const long long ts0 = P.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const int nsw = wg_bond_small(P, S, b, step, Ap, Bp, p, q, rm, ck, ck1, n1, n2, Dl, wide ? 1 : 0, io.rank_out, lds);
+        if (tid == 0) {
+            P.sweep_stats[b] += nsw;
+            if (P.prof) {
+                if (P.prof_step < 0 || P.prof_step == step) P.prof[(long long)b * 16 + 3] += (long long)__builtin_amdgcn_s_memtime() - ts0;
+                if (step < 120) P.prof[(long long)P.tt.batch * 16 + (long long)b * 120 + step] = (2LL << 48) | ((long long)p << 32) | (long long)nsw;
+            }
+        }
+        __syncthreads();
+        return;
     }
 
     // fused apply: the right core is still A_{k+1} x_{k+1}.  Wide steps with r_mid >= p get the fused merge below; the
