@@ -2639,7 +2639,9 @@ __device__ bool wg_fused_merge(const CompressArgs& P, int b, int k, int p, int q
 // Same conventions as the Householder route: units of s0 = max |M|, negligible rows (norm^2 <= aneg) are left alone and come out as
 // exact zeros, convergence when a whole sweep rotates nothing (|g| <= tol sqrt(a b), tol = jtol_mult sqrt(q) eps).
 // -------------------------------------------------------------------------------------------------
+#ifndef SMALL_STEP_PMAX
 #define SMALL_STEP_PMAX 8
+#endif
 #define SMALL_STEP_QMAX 256
 __device__ __noinline__ int wg_bond_small(const CompressArgs& P, const BondCtx& S, int b, int step, View Ap, View Bp, int p, int q, int rm,
                                           double* ck, double* ck1, int n1, int n2, int Dl, int wide, long long* rank_out, double* lds) {
@@ -2680,7 +2682,7 @@ __device__ __noinline__ int wg_bond_small(const CompressArgs& P, const BondCtx& 
     }
     amax = unif64(wg_max(amax, S.red));
     const double aneg = P.jneg_mult * P.jneg_mult * (double)q * DBL_EPSILON * DBL_EPSILON * amax;
-    const double tol = P.jtol_mult * sqrt((double)q) * DBL_EPSILON;
+    const double tol = P.jtol_mult * sqrt((double)q) * DBL_EPSILON, tol2 = tol * tol;
     if (tid == 0) S.scal[0] = aneg;
     // ---- one-sided Jacobi on the rows ----
     const int pe = p + (p & 1), half = pe >> 1;
@@ -2698,15 +2700,29 @@ __device__ __noinline__ int wg_bond_small(const CompressArgs& P, const BondCtx& 
                 if (j >= p) continue;                                  // bye
                 lds_f64* xi = Ms + i * LDQ;
                 lds_f64* xj = Ms + j * LDQ;
+                // (rows of up to 256 entries: four per lane in registers between the dot products and the rotation)
+                double u[4], v[4];
                 double a = 0.0, b_ = 0.0, g = 0.0;
-                for (int c = lane; c < q; c += 64) { const double u = xi[c], v = xj[c]; a = fma(u, u, a); b_ = fma(v, v, b_); g = fma(u, v, g); }
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int c = lane + 64 * t4;
+                    u[t4] = (c < q) ? xi[c] : 0.0; v[t4] = (c < q) ? xj[c] : 0.0;
+                    a = fma(u[t4], u[t4], a); b_ = fma(v[t4], v[t4], b_); g = fma(u[t4], v[t4], g);
+                }
                 a = wave_sum(a); b_ = wave_sum(b_); g = wave_sum(g);
                 if (a <= aneg || b_ <= aneg) continue;
-                if (fabs(g) <= tol * sqrt(a) * sqrt(b_)) continue;
-                const double zeta = (b_ - a) / (2.0 * g);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
-                const double cs = 1.0 / sqrt(fma(t, t, 1.0)), sn = cs * t;
-                for (int c = lane; c < q; c += 64) { const double u = xi[c], v = xj[c]; xi[c] = cs * u - sn * v; xj[c] = sn * u + cs * v; }
+                if (g * g <= tol2 * a * b_) continue;
+                // t = tan(theta) = sign(d) h / (|d| + sqrt(d^2 + h^2)), d = b - a, h = 2 g: hardware seeds are enough for t (it only sets the
+                // speed of convergence); c = rsqrt(1 + t^2) with Newton steps so that c^2 + s^2 = 1 to rounding (as in the image Jacobi)
+                const double dd = b_ - a, hh = g + g;
+                const double hyp = __builtin_amdgcn_sqrt(fma(dd, dd, hh * hh));
+                const double t = copysign(hh * __builtin_amdgcn_rcp(fabs(dd) + hyp), hh * dd);
+                const double cs = fast_rsqrt2(fma(t, t, 1.0)), sn = cs * t;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int c = lane + 64 * t4;
+                    if (c < q) { xi[c] = cs * u[t4] - sn * v[t4]; xj[c] = sn * u[t4] + cs * v[t4]; }
+                }
                 if (lane < p) { const double u = Es[i * 17 + lane], v = Es[j * 17 + lane]; Es[i * 17 + lane] = cs * u - sn * v; Es[j * 17 + lane] = sn * u + cs * v; }
                 rotated = 1;
             }
