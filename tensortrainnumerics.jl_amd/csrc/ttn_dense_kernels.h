@@ -731,6 +731,126 @@ __device__ inline void wg_syrk(int p, int q, View A, View G, double alpha, doubl
     TTN_SETPRIO_BASE();
 }
 
+// Two Gram products of at most 64 rows in ONE pass (route F: A'^T A' with B' B'^T, and its two a-posteriori checks): a 64 x 64 x 128
+// product is 1 Mflop and ~25 k clk of descriptor, tables, staging latency and barriers — paired, the two share every one of them
+// (20 tiles on the waves instead of 10, both operands' chunks behind the same barrier).  G1 through the view in dsc->C, G2 = column-
+// major with leading dimension 128 at the pointer in dsc->amax; dsc: m = p1, n = p2, k = q1, pad = q2, A = A1, B = A2, alpha, beta = alpha2.
+__device__ TTN_NI_GEMM void wg_syrk_pair_impl(const GemmDesc* dsc_, double* lds) {
+    const lds_gdesc* dsc = (const lds_gdesc*)dsc_;
+    constexpr int KC16 = 3, KC = 16 * KC16, RG = TTN_WG / 16, JMAX = (64 + RG - 1) / RG, LD = 81;
+    constexpr int MAXT = (20 + TTN_NWAVES - 1) / TTN_NWAVES;
+    static_assert(2 * KC * LD <= GEMM_LDS_DOUBLES, "two operand chunks");
+    const int p1 = uni32(dsc->m), p2 = uni32(dsc->n), q1 = uni32(dsc->k), q2 = uni32(dsc->pad);
+    const View A1 = ldsView(&dsc->A), A2 = ldsView(&dsc->B), C1 = ldsView(&dsc->C);
+    const double alpha1 = unif64(dsc->alpha), alpha2 = unif64(dsc->beta);
+    gmem_wf64* G2 = (gmem_wf64*)(unsigned long long)uni64((long long)dsc->amax);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    lds_f64* Cs = (lds_f64*)lds;                                    // operand o: Cs[o * KC * LD + kk * LD + row]
+    lds_i32* rowT = (lds_i32*)(lds + GEMM_LDS_DOUBLES + 32);       // 64 + 64
+    lds_i32* colT1 = rowT + 128;                                    // q1
+    lds_i32* colT2 = colT1 + q1;                                    // q2
+    gmem_f64* Ag1 = (gmem_f64*)A1.p;
+    gmem_f64* Ag2 = (gmem_f64*)A2.p;
+    for (int i = tid; i < 128; i += TTN_WG) rowT[i] = (i < 64) ? ((i < p1) ? (int)ix(A1.r, i) : 0) : ((i - 64 < p2) ? (int)ix(A2.r, i - 64) : 0);
+    for (int i = tid; i < q1; i += TTN_WG) colT1[i] = (int)ix(A1.c, i);
+    for (int i = tid; i < q2; i += TTN_WG) colT2[i] = (int)ix(A2.c, i);
+    int t_o[MAXT], t_r[MAXT], t_c[MAXT];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        const int t = wave + u * TTN_NWAVES, o = (t >= 10) ? 1 : 0, tt = t - 10 * o;
+        int tr = 0, base = 0;
+        while (base + tr + 1 <= tt) { base += tr + 1; ++tr; }
+        const int pp_o = ((o ? p2 : p1) + 15) >> 4;                   // tile rows of that operand
+        t_o[u] = uni32(o); t_r[u] = uni32((t < 20 && tr < pp_o) ? tr : -1); t_c[u] = uni32(tt - base);
+    }
+    mfma_acc_t acc[MAXT];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) acc[u] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+    const int fx = tid & 15, sy = tid >> 4;
+    const int qmax = (q1 > q2) ? q1 : q2;
+    double v1[JMAX][KC16], v2[JMAX][KC16];
+    __syncthreads();
+#define SYRK2_LOAD(K0)                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < JMAX; ++j) {                                                                   \
+        const int row = sy + RG * j;                                                                                    \
+        const int ro1 = (row < p1) ? rowT[row] : 0, ro2 = (row < p2) ? rowT[64 + (row < 64 ? row : 0)] : 0;             \
+        _Pragma("unroll") for (int u = 0; u < KC16; ++u) {                                                               \
+            const int kk = (K0) + fx + 16 * u;                                                                          \
+            v1[j][u] = Ag1[(row < p1 && kk < q1) ? ro1 + colT1[kk] : 0];                                                \
+            v2[j][u] = Ag2[(row < p2 && kk < q2) ? ro2 + colT2[kk] : 0];                                                \
+        }                                                                                                               \
+    }
+    SYRK2_LOAD(0)
+    for (int k0 = 0; k0 < qmax; k0 += KC) {
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int row = sy + RG * j;
+#pragma unroll
+            for (int u = 0; u < KC16; ++u) {
+                const int kl = fx + 16 * u;
+                if (row < 64) {
+                    Cs[kl * LD + row] = (row < p1 && k0 + kl < q1) ? v1[j][u] : 0.0;
+                    Cs[KC * LD + kl * LD + row] = (row < p2 && k0 + kl < q2) ? v2[j][u] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        if (k0 + KC < qmax) { SYRK2_LOAD(k0 + KC) }
+        const int ksteps = (qmax - k0 < KC) ? (qmax - k0 + 3) >> 2 : KC / 4;
+        for (int ks = 0; ks < ksteps; ++ks) {
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) {
+                if (t_r[u] >= 0) {
+                    const lds_f64* rowp = Cs + t_o[u] * (KC * LD) + (4 * ks + lk) * LD + li;
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[16 * t_r[u]], rowp[16 * t_c[u]], acc[u], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef SYRK2_LOAD
+    gmem_wf64* G1 = (gmem_wf64*)C1.p;
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        if (t_r[u] < 0) continue;
+        const int po = t_o[u] ? p2 : p1;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int gi = 16 * t_r[u] + lk + 4 * reg, gj = 16 * t_c[u] + li;
+            if (gi < po && gj < po) {
+                if (t_o[u] == 0) {
+                    const double val = alpha1 * acc[u][reg];
+                    G1[ix(C1.r, gi) + ix(C1.c, gj)] = val;
+                    if (t_r[u] != t_c[u]) G1[ix(C1.r, gj) + ix(C1.c, gi)] = val;
+                } else {
+                    const double val = alpha2 * acc[u][reg];
+                    G2[gi + 128 * gj] = val;
+                    if (t_r[u] != t_c[u]) G2[gj + 128 * gi] = val;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// G1 = alpha1 A1 A1^T and G2 = alpha2 A2 A2^T (G2: column-major, leading dimension 128)
+__device__ inline void wg_syrk_pair(int p1, int q1, View A1, View G1, double alpha1, int p2, int q2, View A2, double* G2_ld128, double alpha2, double* lds) {
+    if (p1 > 64 || p2 > 64 || q1 + q2 > SYRK_QMAX - 128) {
+        wg_syrk(p1, q1, A1, G1, alpha1, lds);
+        wg_syrk(p2, q2, A2, mkview(G2_ld128, plain(1), plain(128)), alpha2, lds);
+        return;
+    }
+    GemmDesc* dsc = reinterpret_cast<GemmDesc*>(lds + GEMM_LDS_DOUBLES);
+    __syncthreads();
+    if (threadIdx.x == 0) { dsc->m = p1; dsc->n = p2; dsc->k = q1; dsc->pad = q2; dsc->A = A1; dsc->B = A2; dsc->C = G1; dsc->alpha = alpha1; dsc->beta = alpha2;
+                            dsc->amax = (unsigned long long*)G2_ld128; }
+    __syncthreads();
+    TTN_SETPRIO_GEMM();
+    wg_syrk_pair_impl(dsc, lds);
+    TTN_SETPRIO_BASE();
+}
+
 // -------------------------------------------------------------------------------------------------
 // wg_gemm_ra: C = alpha * A B for a SHORT, SHALLOW A (m <= 64 rows, k <= 128) and any n — the right factor of a bond step
 // (sqrt(S) V^T = X^T M: 64 x 384 x 128), route F's two output products (64 x 128 x 64; the left one is passed transposed).
@@ -1908,7 +2028,8 @@ struct CompressArgs {
                            // Diagnostic bits (TTN_FAST): 2 no eigensolver in route G (Cholesky + Jacobi), 4 none in route F,
                            // 8 no diagonal-left shortcut in route F, 16 no Jacobi polish after a failed conditioning test, 32 no CholeskyQR2,
                            // 64 Gram / reflector / check matrices in their own scratch instead of the dead T buffer, 128 two-pass fused merge,
-                           // 512 no barrier-free (direct) form of the one-pass merge, 1024 no LDS-only path for the tiny steps
+                           // 512 no barrier-free (direct) form of the one-pass merge, 1024 no LDS-only path for the tiny steps,
+                           // 4096 route F's Gram products one at a time
     // fused apply (ttn_apply_compress): psi = A * x is never materialised.  During the FIRST L->R sweep core k+1 of psi
     // is still virtual (= A_{k+1} applied to x_{k+1}); psi's ranks already hold A.rks .* x.rks.
     int fused;
@@ -2905,9 +3026,10 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
         const View Ccv = mkview(S.Cc, plain(1), plain(128));
         bool diagA = false;
         if (ok) {
-            wg_syrk(rm, p, tview(Ap), Gav, 1.0 / (sA * sA), lds);          // A'^T A'
-            FINE_MARK(1)
-            wg_syrk(rm, q, Bp, Gbv, 1.0 / (sB * sB), lds);          // B' B'^T
+            if (P.fast & 4096) {
+                wg_syrk(rm, p, tview(Ap), Gav, 1.0 / (sA * sA), lds);          // A'^T A'
+                wg_syrk(rm, q, Bp, Gbv, 1.0 / (sB * sB), lds);          // B' B'^T
+            } else wg_syrk_pair(rm, p, tview(Ap), Gav, 1.0 / (sA * sA), rm, q, Bp, S.Gb, 1.0 / (sB * sB), lds);     // A'^T A' and B' B'^T in one pass
             FINE_MARK(2)
             PROF_MARK(8)
             // A' = U D^(1/2) with orthonormal U (the left core of a bond step is left as U sqrt(S) by the step before it, so every
@@ -3024,9 +3146,10 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             wg_gemm(rk, q, rm, tview(mkview(S.T3, plain(1), plain(128))), Bp, Rft, 1.0, 0.0, lds);
             }
             // a-posteriori check: Lf^T Lf = Sigma, Rf Rf^T = Sigma
-            wg_syrk(rk, p, tview(Lft), mkview(S.T1, plain(1), plain(128)), 1.0, lds);
-            FINE_MARK(10)
-            wg_syrk(rk, q, Rft, mkview(S.T2, plain(1), plain(128)), 1.0, lds);
+            if (P.fast & 4096) {
+                wg_syrk(rk, p, tview(Lft), mkview(S.T1, plain(1), plain(128)), 1.0, lds);
+                wg_syrk(rk, q, Rft, mkview(S.T2, plain(1), plain(128)), 1.0, lds);
+            } else wg_syrk_pair(rk, p, tview(Lft), mkview(S.T1, plain(1), plain(128)), 1.0, rk, q, Rft, S.T2, 1.0, lds);
             FINE_MARK(11)
             const double e1 = wg_check_diag_tab(S.sigs, S.T1, 128, rk, s0, S.Ts, S.red);
             const double e2 = wg_check_diag_tab(S.sigs, S.T2, 128, rk, s0, S.Ts, S.red);
