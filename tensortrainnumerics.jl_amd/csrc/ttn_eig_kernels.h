@@ -92,6 +92,132 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
     double a[CW];
 #pragma unroll
     for (int j = 0; j < CW; ++j) a[j] = actv ? Gg[i + (long long)ldg * (CW * c + j)] : 0.0;
+#ifndef TTN_TRIDIAG_V1
+    // ---- schedule (round 2): the reflector is formed in TWO halves around a barrier, and the matrix-vector product runs on the
+    // known column x~ instead of v.  v_k = x~_k - alpha_k e_{k+1} (x~_k = column k of the current matrix below the diagonal), so
+    //   A v_k = A x~_k - alpha_k A[:, k+1],   A[:, k+1] = row k+1 = the look-ahead buffer —
+    // the product needs x~_k only, which wave 0 has ~100 clk after w_{k-1}, not the scalars alpha, beta that take it another ~900.
+    // Per column k, three LDS barriers as before:
+    //   S1  all: y = A x~_k (partial sums)            | wave 0 first: beta_k, v_k -> LDS / global, (d_k, e_k, beta_k)
+    //   S2  wave 0: p = beta (y - alpha row_{k+1}), w_k = p - (beta/2)(p'v) v
+    //   S3  others: A -= v w' + w v', row k+2 out      | wave 0: x~_{k+1} -> LDS, ||x~||^2, alpha_{k+1}   (first half of reflector k+1)
+    // i.e. the product overlaps the second half of the reflector and the update its first half: 2.05 k clk of dependent work per
+    // column instead of 2.4 k.
+    lds_f64* xt = L + 1664;                                       // x~ of the current column (128)
+    if (actv && i == 0) {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) wL[CW * c + j] = a[j];      // row 0 (wL is free here)
+    }
+    if (actv && i == 1) {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) xnext[CW * c + j] = a[j];
+    }
+    __syncthreads();
+    // wave 0's state of the reflector in flight: x~ (two entries per lane), alpha, v'v / 2, the diagonal entry
+    double rx0 = 0.0, rx1 = 0.0, ralpha = 0.0, rden = 0.0, rdg = 0.0;
+    if (wave == 0) {
+        rx0 = (lane > 0) ? wL[lane] : 0.0; rx1 = TWO ? wL[lane + 64] : 0.0;
+        const double xk1 = wL[1];
+        rdg = wL[0];
+        xt[lane] = rx0; xt[lane + 64] = rx1;
+        const double s2 = wave64_sum_mfma(fma(rx0, rx0, rx1 * rx1));
+        ralpha = (s2 > 0.0) ? -copysign(s2 * fast_rsqrt2(s2), xk1) : 0.0;
+        rden = s2 - ralpha * xk1;
+    }
+    for (int k = 0; k < N - 2; ++k) {
+        lds_f64* vL = (k & 1) ? vbuf1 : vbuf0;
+        lds_barrier();                                             // x~_k, row k+1 (xnext) are visible; update k-1 is done
+        const bool live = actv && (CW * (c + 1) > k + 1) && ((TWO ? 64 * (wave & 1) : 0) + 63 > k);
+        double v0 = 0.0, v1 = 0.0, w0 = 0.0, w1 = 0.0, bta = 0.0;
+        // ---- S1 ----
+        if (wave == 0) {
+#ifdef TTN_TRIDIAG_PRIO
+            __builtin_amdgcn_s_setprio(TTN_TRIDIAG_PRIO);          // the serial chain of the column ahead of everybody's parallel work
+#endif
+            if (rden > 0.0) { bta = fast_rcp(rden); bta = fma(fma(-rden, bta, 1.0), bta, bta); }
+            v0 = rx0 - ((lane == k + 1) ? ralpha : 0.0); v1 = rx1 - ((lane + 64 == k + 1) ? ralpha : 0.0);
+            vL[lane] = v0; vL[lane + 64] = v1;
+            typedef __attribute__((address_space(1))) double gdouble;
+            gdouble* vg = (gdouble*)(unsigned long long)(Vst + k * 128);
+            vg[lane] = v0; vg[lane + 64] = v1;
+            if (lane == 0) { dg[k] = rdg; e[k] = ralpha; beta[k] = bta; }
+        }
+        if (live) {
+            double xreg[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) xreg[h] = xt[CW * c + 16 * h + (lane & 15)];
+            double pp = 0.0;
+            asm volatile("s_nop 1");
+#define EIG_MV(j) fmac_bcast<j>(pp, xreg[0], a[j]);
+            EIG_BCAST16(EIG_MV)
+#undef EIG_MV
+            if constexpr (NH == 2) {
+#define EIG_MV(j) fmac_bcast<j>(pp, xreg[1], a[16 + j]);
+                EIG_BCAST16(EIG_MV)
+#undef EIG_MV
+            }
+            part[c * 128 + i] = pp;
+        } else if (actv) part[c * 128 + i] = 0.0;
+        lds_barrier();
+        // ---- S2 ----
+        lds_f64* xn_r = (k & 1) ? xnext + 1152 : xnext;          // row k+1 before update k (= column k+1 of the matrix the product used)
+        lds_f64* xn_w = (k & 1) ? xnext : xnext + 1152;          // written this step (row k+2 after update k)
+        if (wave == 0) {
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) { p0 += part[cc * 128 + lane]; if (TWO) p1 += part[cc * 128 + lane + 64]; }
+            p0 = bta * fma(-ralpha, xn_r[lane], p0); p1 = TWO ? bta * fma(-ralpha, xn_r[lane + 64], p1) : 0.0;
+            const double Kc = 0.5 * bta * wave64_sum_mfma(fma(p0, v0, p1 * v1));
+            w0 = fma(-Kc, v0, p0); w1 = fma(-Kc, v1, p1);
+            wL[lane] = w0; if (TWO) wL[lane + 64] = w1;
+        }
+        lds_barrier();
+        // ---- S3 ----
+        if (wave == 0 && k + 1 < N - 2) {
+            // column k+1 of the updated matrix: x - v w_{k+1} - w v_{k+1}; first half of reflector k+1
+            const double wk1 = wL[k + 1], vk1 = vL[k + 1];
+            const double c0 = fma(-v0, wk1, fma(-w0, vk1, xn_r[lane]));
+            const double c1 = TWO ? fma(-v1, wk1, fma(-w1, vk1, xn_r[lane + 64])) : 0.0;
+            const int kk = k + 1;
+            rdg = (kk < 64) ? readlane_f64(c0, kk) : readlane_f64(c1, kk - 64);
+            const double xk1 = (kk + 1 < 64) ? readlane_f64(c0, kk + 1) : readlane_f64(c1, kk + 1 - 64);
+            rx0 = (lane > kk) ? c0 : 0.0; rx1 = (TWO && lane + 64 > kk) ? c1 : 0.0;
+            xt[lane] = rx0; xt[lane + 64] = rx1;
+            const double s2 = wave64_sum_mfma(fma(rx0, rx0, rx1 * rx1));
+            ralpha = (s2 > 0.0) ? -copysign(s2 * fast_rsqrt2(s2), xk1) : 0.0;
+            rden = s2 - ralpha * xk1;
+        }
+        if (wave == 0) {
+#ifdef TTN_TRIDIAG_PRIO
+#ifdef TTN_EIG_PRIO
+            __builtin_amdgcn_s_setprio(TTN_EIG_PRIO);
+#else
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
+        }
+        if (live) {
+            // A -= v w' + w v'
+            double vreg[NH], wreg[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) { vreg[h] = vL[CW * c + 16 * h + (lane & 15)]; wreg[h] = wL[CW * c + 16 * h + (lane & 15)]; }
+            const double nvi = -vL[i], nwi = -wL[i];
+            asm volatile("s_nop 1");
+#define EIG_UP(j) fmac_bcast<j>(a[j], wreg[0], nvi); fmac_bcast<j>(a[j], vreg[0], nwi);
+            EIG_BCAST16(EIG_UP)
+#undef EIG_UP
+            if constexpr (NH == 2) {
+#define EIG_UP(j) fmac_bcast<j>(a[16 + j], wreg[1], nvi); fmac_bcast<j>(a[16 + j], vreg[1], nwi);
+                EIG_BCAST16(EIG_UP)
+#undef EIG_UP
+            }
+            if (i == k + 2) {
+#pragma unroll
+                for (int j = 0; j < CW; ++j) xn_w[CW * c + j] = a[j];
+            }
+        }
+    }
+#else
     // prologue: rows 0 and 1 of the matrix; reflector 0
     if (actv && i == 0) {
 #pragma unroll
@@ -195,6 +321,7 @@ __device__ __noinline__ void wg_tridiag(const double* Gg, int ldg, double* Vst, 
             }
         }
     }
+#endif
     // the last 2 x 2 block
     __syncthreads();
     if (actv && i == N - 2 && c == NC - 1) { dg[N - 2] = a[CW - 2]; e[N - 2] = a[CW - 1]; }
