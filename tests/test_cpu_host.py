@@ -224,3 +224,29 @@ def test_reorder_swap_lists_match_oracle():
     # the two orderings are inverse site maps
     a, b = T.reorder_perm(3, 4, "interleaved"), T.reorder_perm(3, 4, "serial")
     assert [b[a[i]] for i in range(12)] == list(range(12))
+
+
+def test_compress_kernel_register_budget(tmp_path):
+    """k_compress (512-thread build, the one the benchmark times) runs at the 128-VGPR limit with its bond step force-inlined; one more
+    call site with live views in that function once cost it 280 more spilled VGPRs and 7 % of the benchmark without any test noticing
+    (round 2: the runtime A/B switch compared two arms of the same, slower binary).  The compiler's own report is the guard."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "tensortrainnumerics.jl_amd", "csrc", "ttn_wg512.hip")
+    out = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", "-c",
+                          "-Rpass-analysis=kernel-resource-usage", src, "-o", str(tmp_path / "wg512.o")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = out.stderr
+    i = rep.find("k_compress")
+    assert i >= 0, "no resource report for k_compress"
+    blk = rep[i:i + 4000]
+    spill = int(re.search(r"VGPRs Spill: (\d+)", blk).group(1))
+    scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
+    occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", blk).group(1))
+    assert occ == 4, occ                                   # two 512-thread workgroups per CU
+    assert spill <= 260 and scratch <= 1700, (spill, scratch)
