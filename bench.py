@@ -86,8 +86,27 @@ def _cpu_worker(args):
         return time.perf_counter() - t0
 
 
+def cgroup_cpu_quota():
+    """Effective CPU quota of this process's cgroup in cores (cpu.max = "<quota> <period>" / "max <period>"), or None."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            with open(path) as fh:
+                q, per = fh.read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+        except (OSError, ValueError):
+            pass
+    try:                                            # cgroup v1
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+            q = float(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            per = float(fh.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def host_info():
-    info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+    info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_quota_cores": cgroup_cpu_quota()}
     try:
         with open("/proc/cpuinfo") as fh:
             for line in fh:
@@ -112,6 +131,9 @@ def cpu_baseline(d, rank, budget_s=20.0):
     (i) one independent train per process, 1 BLAS thread each; (ii) one train with all BLAS threads.  value = best."""
     import multiprocessing as mp
     cores = max(1, len(os.sched_getaffinity(0)))
+    quota = cgroup_cpu_quota()
+    if quota:                                       # more processes than twice the quota only add scheduling noise
+        cores = max(1, min(cores, 2 * int(quota + 0.999)))
     t1 = _cpu_worker((d, rank, 30, 1, False, 1))                  # calibrate on one train, one thread
     reps = max(1, min(8, int(budget_s / max(t1, 1e-3))))
     ctx = mp.get_context("spawn")
@@ -124,8 +146,11 @@ def cpu_baseline(d, rank, budget_s=20.0):
     single = d / t1
     tall = _cpu_worker((d, rank, 30, max(1, min(3, reps)), False, cores)) / max(1, min(3, reps))
     one_train_all_threads = d / tall
-    cands = [(multi, cores, "%d procs x 1 BLAS thread" % cores), (single, 1, "1 proc x 1 BLAS thread"),
-             (one_train_all_threads, cores, "1 proc x %d BLAS threads" % cores)]
+    # `cores` in the record = the EFFECTIVE parallelism: the box's CPU share is a cgroup quota far below the visible hardware
+    # threads, so N processes deliver multi / single cores' worth of work, not N (round 2 printed the process count: 256)
+    eff = max(1.0, multi / single)
+    cands = [(multi, round(eff, 1), "%d procs x 1 BLAS thread" % cores), (single, 1, "1 proc x 1 BLAS thread"),
+             (one_train_all_threads, round(max(1.0, one_train_all_threads / single), 1), "1 proc x %d BLAS threads" % cores)]
     value, used, how = max(cands)
     # the reference-FAITHFUL flavour (with the orthogonalize that _tt_bond_truncate! computes and tt_compress! discards,
     # src/tt_tools.jl:769,779) on one train and one core, if the lean timing says it fits ~15 s
@@ -139,7 +164,8 @@ def cpu_baseline(d, rank, budget_s=20.0):
            "sample": f"{cores} procs x {reps} trains of d={d} rank={rank} (lean oracle = reference algorithm without the discarded "
                      f"orthogonalize, NumPy+LAPACK gesdd); best of: {how}",
            "trains_per_core_all_cores": round(multi, 2), "one_train_one_thread": round(single, 2),
-           "one_train_all_threads": round(one_train_all_threads, 2), "host": host_info()}
+           "one_train_all_threads": round(one_train_all_threads, 2), "processes": cores,
+           "parallel_efficiency": round(multi / single / cores, 4), "host": host_info()}
     if faithful:
         out["faithful_single_core"] = round(faithful, 2)
     return out
@@ -165,6 +191,208 @@ def verify_against_oracle(T, dy, seeds_by_slot, d, r, slots):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# the compress step on one configuration (headline C3, sub-record C2)
+# ------------------------------------------------------------------------------------------------------------------
+def run_compress_config(T, D, d, r, B, steps, warmup, rank, world, barrier, dist, red_device, verify):
+    """W untimed + K timed launches of ttn_apply_compress over B synthetic trains per rank; returns the measured record of
+    this rank's view (value = whole job: max-over-ranks wall time)."""
+    A = T.Delta(d)
+    dA = T.DeviceTTO(A)
+    x0 = T.rand_tt((2,) * d, r, seed=30)
+    dx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=B)
+    seeds = [30 + g for g in T.shard.weak_train_ids(rank, world, B)]     # distinct synthetic trains, seeds 30 + global index
+    for b, sd in enumerate(seeds):
+        dx.upload(b, T.rand_tt((2,) * d, r, seed=sd))
+    ycap = [a * c for a, c in zip(A.tto_rks, x0.ttv_rks)]
+    dy = T.DeviceTT((2,) * d, ycap, batch=B)
+    for _ in range(warmup):
+        D.apply_compress(dA, dx, dy, r)
+    D.compress_status(dy)                                      # raises if any Jacobi SVD failed to converge
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        # ttn_apply_compress: apply fused into the first L->R sweep of k_compress (y = A*x never exists in HBM)
+        D.event_record(2 * i)
+        D.apply_compress(dA, dx, dy, r)
+        D.event_record(2 * i + 1)
+    barrier_free_sync(D)
+    elapsed = T.shard.max_over_ranks(time.perf_counter() - t0, dist, device=red_device)
+    if dist is not None:
+        dist.barrier()
+    sweeps = D.compress_status(dy)
+    kms = [D.event_elapsed_ms(2 * i, 2 * i + 1) for i in range(steps)]
+    k_avg_s = sum(kms) / len(kms) / 1e3
+    out_rks, _ = dy.ranks(0)
+    flops = sweep_algorithmic_flops(d, ycap, None, r) * B
+    rec = {"d": d, "rank": r, "batch": B, "steps": steps, "warmup": warmup, "elapsed": elapsed, "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "value": round(T.shard.cores_per_second(world, B, d, elapsed / steps), 1), "k_avg_s": k_avg_s, "flops": flops,
+           "achieved": flops / k_avg_s / 1e12, "frac": round(flops / k_avg_s / 1e12 / FP64_PEAK_TFLOPS, 4), "out_rks": out_rks,
+           "jacobi_sweeps": sweeps[0]}
+    if verify:
+        slots = sorted({0, B // 2, B - 1})
+        n, worst = verify_against_oracle(T, dy, seeds, d, r, slots)
+        rec["verified"], rec["verified_max_rel_diff"] = n, float("%.3e" % worst)
+    dx.free(); dy.free(); dA.free()
+    return rec
+
+
+def barrier_free_sync(D):
+    import torch
+    D.sync()
+    torch.cuda.synchronize()
+
+
+def batch_sweep(T, D, d, r):
+    """The same step at B = 1, 8, 64, 128, 256 (B = 1: latency of one train).  At 128 and 256 trains both kernel builds are timed
+    (TTN_WG512 is read per launch): `build` names the one the library picks by itself."""
+    A = T.Delta(d)
+    dA = T.DeviceTTO(A)
+    x0 = T.rand_tt((2,) * d, r, seed=30)
+    ycap = [a * c for a, c in zip(A.tto_rks, x0.ttv_rks)]
+    out = []
+    for Bs in (1, 8, 64, 128, 256):
+        sx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=Bs)
+        for b in range(Bs):
+            sx.upload(b, T.rand_tt((2,) * d, r, seed=30 + b))
+        sy = T.DeviceTT((2,) * d, ycap, batch=Bs)
+
+        def timed():
+            for _ in range(2):
+                D.apply_compress(dA, sx, sy, r)
+            D.sync()
+            nrep = 5
+            ts = time.perf_counter()
+            for _ in range(nrep):
+                D.apply_compress(dA, sx, sy, r)
+            D.sync()
+            tb = (time.perf_counter() - ts) / nrep
+            D.compress_status(sy)
+            return tb
+        tb = timed()
+        rec = {"batch": Bs, "value": round(Bs * d / tb, 1), "unit": "TT cores/s", "ms_per_step": round(tb * 1e3, 3)}
+        if Bs >= 128 and "TTN_WG512" not in os.environ:
+            alt = {}
+            for flag in ("0", "1"):
+                os.environ["TTN_WG512"] = flag
+                alt["wg1024" if flag == "0" else "wg512"] = round(timed() * 1e3, 3)
+            del os.environ["TTN_WG512"]
+            rec["ms_per_step_by_build"] = alt
+        out.append(rec)
+        sx.free()
+        sy.free()
+    dA.free()
+    return out
+
+
+def drop_in_latency(T, d, r):
+    """What a drop-in user of the STATELESS entry points gets for ONE train (julia/TTNBackend.jl binds `*` and `tt_compress!` to
+    them: src/tt_operations.jl:101, src/tt_tools.jl:772): host buffers in, host buffers out — ttn_apply_f64 (upload x and A,
+    download the 11.4 MB y) then ttn_compress_f64 (upload y, download the result).  PCIe-inclusive wall time, never `value`."""
+    A = T.Delta(d)
+    x = T.rand_tt((2,) * d, r, seed=30)
+    t_apply, t_comp = [], []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        y = A * x                                   # ttn_apply_f64
+        t1 = time.perf_counter()
+        T.tt_compress_(y, r)                        # ttn_compress_f64
+        t2 = time.perf_counter()
+        t_apply.append(t1 - t0)
+        t_comp.append(t2 - t1)
+    ta, tc = min(t_apply[1:]), min(t_comp[1:])
+    return {"what": "ttn_apply_f64 + ttn_compress_f64 on one train, host buffers in and out (PCIe-inclusive; best of 3 after one warm-up)",
+            "ms_apply": round(ta * 1e3, 3), "ms_compress": round(tc * 1e3, 3), "ms_total": round((ta + tc) * 1e3, 3),
+            "value": round(d / (ta + tc), 1), "unit": "TT cores/s"}
+
+
+def pmc_busy_fractions():
+    """MFMA-pipe and VALU busy fractions of k_compress from the newest committed PMC summary (profiles/r*_pmc.json, separate
+    rocprofv3 --pmc passes of the default bench command): what the chip actually does, beside the algorithmic `frac`."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
+        try:
+            with open(path) as fh:
+                j = json.load(fh)
+            dv = j.get("derived") or {}
+            if "mfma_pipe_busy_frac" in dv:
+                best = {"file": os.path.relpath(path, ROOT), "mfma_pipe_busy_frac": round(dv["mfma_pipe_busy_frac"], 4),
+                        "valu_busy_frac": round(dv.get("valu_busy_frac", 0.0), 4),
+                        "mfma_f64_mops_per_launch": j.get("k_compress", {}).get("SQ_INSTS_VALU_MFMA_MOPS_F64_per_launch")}
+        except (OSError, ValueError):
+            pass
+    return best
+
+
+def headline_record(args, head, d, r, B, world):
+    traffic, traffic_upper, traffic_src = None, None, None
+    tpath = os.path.join(ROOT, "profiles", "k_compress_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        if (tj.get("d"), tj.get("rank"), tj.get("batch"), 1) == (d, r, B, world):
+            traffic = tj.get("traffic_bytes_per_launch")
+            traffic_upper = tj.get("traffic_bytes_per_launch_upper")
+            traffic_src = {"file": "profiles/k_compress_traffic.json", "tag": tj.get("tag"), "commit": tj.get("commit"),
+                           "note": "profile-derived (separate --pmc passes), not measured by this run; traffic = WRITE + raw FETCH_SIZE "
+                                   "(lower figure), traffic_upper = WRITE + 2 x FETCH_SIZE (gfx950 counts wide reads at half)"}
+    res = {
+        "metric": "TT cores/sec for QTT Laplacian apply+round, d=%d rank-%d" % (d, r),
+        "value": head["value"], "unit": "TT cores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C3: tt_compress!(Delta(%d)*x, %d), x = rand_tt(dims=2^%d, rank %d), batch of %d independent "
+                               "trains per GPU resident in HBM (seeds 30+i), truncerr=0, sweeps=1" % (d, r, d, r, B),
+                   "d": d, "rank": r, "batch_per_gpu": B, "parallelism": "trains sharded over %d GPU(s), no collective" % world,
+                   "out_ranks": head["out_rks"]},
+        "roofline": {"bound": "mfma", "kernel": "k_compress", "achieved": round(head["achieved"], 3), "peak": FP64_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": head["frac"], "traffic": traffic, "traffic_upper": traffic_upper, "traffic_source": traffic_src,
+                     "achieved_is": "ALGORITHMIC-equivalent TFLOP/s: SURVEY 8d's flop count (merge GEMMs + Golub-Van-Loan dense thin-SVD count) / "
+                                    "measured launch time; the kernel executes far fewer flops than that count (Gram / eigensolver routes): "
+                                    "see pipe_utilisation for what the matrix pipe really does",
+                     "pipe_utilisation": pmc_busy_fractions(),
+                     "algorithmic_flops_per_launch": head["flops"], "avg_launch_ms": round(head["k_avg_s"] * 1e3, 3),
+                     "bond_steps_per_s": round(2 * (d - 1) * B / head["k_avg_s"], 1),
+                     "jacobi_sweeps_per_train": head["jacobi_sweeps"]},
+    }
+    if "verified" in head:
+        res["verified"] = head["verified"]
+        res["verified_max_rel_diff"] = head["verified_max_rel_diff"]
+    return res
+
+
+def guarded_core_sharded(args, T, D, torch, dist, rank, world, red_device, head, extras, c2):
+    """BASELINE config C4 inside the N > 1 line: the core-wise sharded pipeline over the same ranks, after the headline
+    measurement.  Its RCCL point-to-point transport has never run on real multi-GPU hardware, so a WATCHDOG bounds it: if the
+    section has not finished after --core-sharded-timeout seconds, rank 0 prints the headline line with the failure recorded and
+    every rank leaves the process — a hang here must not cost the run its headline number."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(args.core_sharded_timeout):
+            return
+        if rank == 0:
+            res = headline_record(args, head, args.d, args.rank, args.batch, world)
+            res.update(extras)
+            if c2 is not None:
+                res["c2"] = {"value": c2["value"], "ms_per_step": c2["ms_per_step"], "frac": c2["frac"], "verified": c2.get("verified")}
+            res["core_sharded"] = {"error": "core-wise sharded section did not finish within %d s (watchdog)" % args.core_sharded_timeout}
+            print(json.dumps(res), flush=True)
+        os._exit(0)
+
+    th = threading.Thread(target=watchdog, daemon=True)
+    th.start()
+    try:
+        rec = core_sharded_record(args, T, D, torch, dist, rank, world, red_device, B=min(args.batch, 256), steps=3, warmup=1)
+    except Exception as exc:                        # a failure of the sub-record is recorded, not fatal
+        rec = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    done.set()
+    return rec
+
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # launcher
 # ------------------------------------------------------------------------------------------------------------------
 def launch_workers(n, argv):
@@ -182,14 +410,17 @@ def launch_workers(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def bench_core_sharded(args, T, D, torch, dist, rank, world, red_device):
-    """--shard cores: every chain is cut core-wise into `world` segments (pipeline.py), micro-batches of --batch trains are
-    pipelined through the ranks with one boundary-core hand-off per segment boundary, direction and micro-batch.  One STEP
-    = tt_compress!(Delta*x, r) of ALL micro-batches; value = microbatches * batch * d / max-over-ranks step time (strong
-    scaling of a fixed set of chains: the work per GPU shrinks with N).  No roofline/cpu legs: the kernels are the same."""
+def core_sharded_record(args, T, D, torch, dist, rank, world, red_device, B=None, steps=None, warmup=None):
+    """Every chain cut core-wise into `world` segments (pipeline.py), micro-batches of B trains pipelined through the ranks with
+    one boundary-core hand-off per segment boundary, direction and micro-batch.  One STEP = tt_compress!(Delta*x, r) of ALL
+    micro-batches; value = microbatches * B * d / max-over-ranks step time (strong scaling of a fixed set of chains: the work
+    per GPU shrinks with N).  Returns the record on rank 0, None elsewhere.  No roofline/cpu legs: the kernels are the same."""
     import numpy as np
     from ttn_amd import pipeline as PL
-    d, r, B = args.d, args.rank, args.batch
+    d, r = args.d, args.rank
+    B = args.batch if B is None else B
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     M = args.microbatches if args.microbatches > 0 else 2 * world
     A = T.Delta(d)
     lo, hi = PL.extended_range(d, rank, world)
@@ -211,11 +442,11 @@ def bench_core_sharded(args, T, D, torch, dist, rank, world, red_device):
     def step():
         return PL.sharded_apply_compress(backend, transport, rank, world, prepared, hi - lo, r)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         segs = step()
     D.sync()
     torch.cuda.synchronize()
@@ -223,18 +454,28 @@ def bench_core_sharded(args, T, D, torch, dist, rank, world, red_device):
     if dist is not None:
         dist.barrier()
     rks_local = segs[0].ranks(0)[0]
+    for prep in prepared:
+        for h in prep:
+            h.free()
+    if rank != 0:
+        return None
+    return {
+        "metric": "TT cores/sec for QTT Laplacian apply+round, d=%d rank-%d" % (d, r),
+        "value": round(M * B * d / (elapsed / steps), 1), "unit": "TT cores/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C4: tt_compress!(Delta(%d)*x, %d), every chain cut core-wise into %d segments, %d micro-batches "
+                               "of %d trains pipelined through the ranks, boundary-core hand-offs over %s" %
+                               (d, r, world, M, B, "RCCL (xGMI)" if args.backend == "nccl" else args.backend),
+                   "d": d, "rank": r, "batch_per_microbatch": B, "microbatches": M,
+                   "parallelism": "core-wise pipeline over %d GPU(s)" % world, "rank0_segment_out_ranks": rks_local},
+    }
+
+
+def bench_core_sharded(args, T, D, torch, dist, rank, world, red_device):
+    """--shard cores: the core-wise sharded pipeline (BASELINE config C4) as the line of its own."""
+    res = core_sharded_record(args, T, D, torch, dist, rank, world, red_device)
     if rank == 0:
-        res = {
-            "metric": "TT cores/sec for QTT Laplacian apply+round, d=%d rank-%d" % (d, r),
-            "value": round(M * B * d / (elapsed / args.steps), 1), "unit": "TT cores/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C4: tt_compress!(Delta(%d)*x, %d), every chain cut core-wise into %d segments, %d micro-batches "
-                                   "of %d trains pipelined through the ranks, boundary-core hand-offs over %s" %
-                                   (d, r, world, M, B, "RCCL (xGMI)" if args.backend == "nccl" else args.backend),
-                       "d": d, "rank": r, "batch_per_microbatch": B, "microbatches": M,
-                       "parallelism": "core-wise pipeline over %d GPU(s)" % world, "rank0_segment_out_ranks": rks_local},
-        }
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -342,6 +583,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-single", action="store_true", help="skip the batch sweep B = 1, 8, 64, 256")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run check of downloaded trains against the oracle")
+    ap.add_argument("--no-c2", action="store_true", help="skip the C2 (d=20, rank 32) sub-record")
+    ap.add_argument("--no-core-sharded", action="store_true", help="N>1: skip the core-wise sharded (C4) sub-record")
+    ap.add_argument("--core-sharded-timeout", type=int, default=240, help="N>1: watchdog of the C4 sub-record in seconds")
     ap.add_argument("--shard", default="trains", choices=["trains", "cores"],
                     help="N>1: 'trains' (default) = independent trains per GPU, no data-path collective; 'cores' = every chain cut "
                          "core-wise into N segments with boundary-core hand-offs (pipeline.py; micro-batches of --batch trains)")
@@ -407,112 +651,39 @@ def main():
         return bench_op(args, T, D)
     if args.shard == "cores":
         return bench_core_sharded(args, T, D, torch, dist, rank, world, red_device)
-    A = T.Delta(d)
-    dA = T.DeviceTTO(A)
-    x0 = T.rand_tt((2,) * d, r, seed=30)
-    dx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=B)
-    seeds = [30 + g for g in T.shard.weak_train_ids(rank, world, B)]     # distinct synthetic trains, seeds 30 + global index
-    for b, sd in enumerate(seeds):
-        dx.upload(b, T.rand_tt((2,) * d, r, seed=sd))
-    ycap = [a * c for a, c in zip(A.tto_rks, x0.ttv_rks)]
-    dy = T.DeviceTT((2,) * d, ycap, batch=B)
-
+    # ---- the headline step: C3 unless --d / --rank say otherwise -------------------------------------------------------
     def barrier():
         D.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    def step(i=None):
-        # ttn_apply_compress: apply fused into the first L->R sweep of k_compress (y = A*x never exists in HBM)
-        if i is not None:
-            D.event_record(2 * i)
-        D.apply_compress(dA, dx, dy, r)
-        if i is not None:
-            D.event_record(2 * i + 1)
-
-    for _ in range(args.warmup):
-        step()
-    D.compress_status(dy)                                      # raises if any Jacobi SVD failed to converge
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    D.sync()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    elapsed = T.shard.max_over_ranks(elapsed, dist, device=red_device)
-    if dist is not None:
-        dist.barrier()
-    sweeps = D.compress_status(dy)
-    kms = [D.event_elapsed_ms(2 * i, 2 * i + 1) for i in range(args.steps)]
-    k_avg_s = sum(kms) / len(kms) / 1e3
-    out_rks, _ = dy.ranks(0)
-
-    verified = None
-    if rank == 0 and not args.no_verify:
-        slots = sorted({0, B // 2, B - 1})
-        verified = verify_against_oracle(T, dy, seeds, d, r, slots)
-
-    sweep = None
+    head = run_compress_config(T, D, d, r, B, args.steps, args.warmup, rank, world, barrier, dist, red_device,
+                               verify=(rank == 0 and not args.no_verify))
+    extras = {}
     if rank == 0 and not args.no_single:
-        sweep = []
-        for Bs in (1, 8, 64, 256):
-            sx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=Bs)
-            for b in range(Bs):
-                sx.upload(b, T.rand_tt((2,) * d, r, seed=30 + b))
-            sy = T.DeviceTT((2,) * d, ycap, batch=Bs)
-            for _ in range(2):
-                D.apply_compress(dA, sx, sy, r)
-            D.sync()
-            nrep = 5
-            ts = time.perf_counter()
-            for _ in range(nrep):
-                D.apply_compress(dA, sx, sy, r)
-            D.sync()
-            tb = (time.perf_counter() - ts) / nrep
-            D.compress_status(sy)
-            sweep.append({"batch": Bs, "value": round(Bs * d / tb, 1), "unit": "TT cores/s", "ms_per_step": round(tb * 1e3, 3)})
-            sx.free()
-            sy.free()
+        extras["batch_sweep"] = batch_sweep(T, D, d, r)
+        extras["single_train"] = extras["batch_sweep"][0]
+        extras["drop_in"] = drop_in_latency(T, d, r)
+    # ---- BASELINE config C2 (d = 20, rank 32) as a driver-observed sub-record, same op, same batch size (12 ms per step) ----
+    c2 = None
+    if not args.no_c2 and (d, r) == (30, 64):
+        c2 = run_compress_config(T, D, 20, 32, B, max(3, args.steps), 1, rank, world, barrier, dist, red_device,
+                                 verify=(rank == 0 and not args.no_verify))
+    # ---- BASELINE config C4 (cores sharded over the GPUs) as a sub-record of the N > 1 line, guarded by a watchdog ----
+    core_sharded = None
+    if world > 1 and not args.no_core_sharded:
+        core_sharded = guarded_core_sharded(args, T, D, torch, dist, rank, world, red_device, head if rank == 0 else None, extras, c2)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = T.shard.cores_per_second(world, B, d, elapsed / args.steps)
-        flops = sweep_algorithmic_flops(d, ycap, None, r) * B
-        achieved = flops / k_avg_s / 1e12
-        # HBM traffic of the dominant kernel: the rocprofv3 PMC passes of THIS command line, as scratch/collect_profiles.sh
-        # wrote them (counters cannot be read from inside the process).  Reported only when the configuration matches.
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "k_compress_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            if (tj.get("d"), tj.get("rank"), tj.get("batch"), 1) == (d, r, B, world):
-                traffic = tj.get("traffic_bytes_per_launch")
-                traffic_src = {"file": "profiles/k_compress_traffic.json", "tag": tj.get("tag"), "note": "profile-derived (separate --pmc passes), not measured by this run"}
-        res = {
-            "metric": "TT cores/sec for QTT Laplacian apply+round, d=%d rank-%d" % (d, r),
-            "value": round(value, 1), "unit": "TT cores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3: tt_compress!(Delta(%d)*x, %d), x = rand_tt(dims=2^%d, rank %d), batch of %d independent "
-                                   "trains per GPU resident in HBM (seeds 30+i), truncerr=0, sweeps=1" % (d, r, d, r, B),
-                       "d": d, "rank": r, "batch_per_gpu": B, "parallelism": "trains sharded over %d GPU(s), no collective" % world,
-                       "out_ranks": out_rks},
-            "roofline": {"bound": "mfma", "kernel": "k_compress", "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_flops_per_launch": flops, "avg_launch_ms": round(k_avg_s * 1e3, 3),
-                         "bond_steps_per_s": round(2 * (d - 1) * B / k_avg_s, 1),
-                         "jacobi_sweeps_per_train": sweeps[0]},
-        }
-        if verified is not None:
-            res["verified"] = verified[0]
-            res["verified_max_rel_diff"] = float("%.3e" % verified[1])
-        if sweep is not None:
-            res["batch_sweep"] = sweep
-            res["single_train"] = sweep[0]
+        res = headline_record(args, head, d, r, B, world)
+        res.update(extras)
+        if c2 is not None:
+            res["c2"] = {"workload": "C2: tt_compress!(Delta(20)*x, 32), batch of %d trains per GPU" % B, "value": c2["value"], "unit": "TT cores/s",
+                         "ms_per_step": c2["ms_per_step"], "frac": c2["frac"], "verified": c2.get("verified"),
+                         "verified_max_rel_diff": c2.get("verified_max_rel_diff")}
+        if core_sharded is not None:
+            res["core_sharded"] = core_sharded
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(d, r)
         print(json.dumps(res), flush=True)

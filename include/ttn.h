@@ -97,6 +97,11 @@ int ttn_compress(ttn_tt_t psi, int64_t max_bond, double truncerr, int64_t sweeps
  * one query at its end.  If non-null, total_jacobi_sweeps[b] receives the number of Jacobi sweeps train b used in the last call
  * (diagnostics). */
 int ttn_compress_status(ttn_tt_t psi, int64_t* total_jacobi_sweeps);
+/* One query for a whole chain (synchronises once): the most severe failure code recorded on ANY live handle (left in place
+ * there: ttn_compress_status of that handle still reports and clears it) or on a handle that was FREED before anybody queried it
+ * (ttn_tt_free folds an unread code into a library-level word, cleared here).  A device-resident chain that creates and frees
+ * temporaries (RK4 stages, Krylov vectors) needs this once per time step / iteration instead of one query per compress. */
+int ttn_status_all(void);
 
 /* Rank bounds of tt_compress! (k = 0) or one _tt_bond_truncate! (k = 1-based bond).  The reference keeps
  * r = min(length(s), max_bond) singular values (tt_cross_interpolation.jl:152,164), so the rank of a rank-deficient

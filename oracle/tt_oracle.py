@@ -947,6 +947,9 @@ def dmrg_sweep_plan(sweep_schedule: Sequence[int], rmax_schedule: Sequence[int])
         plan.append(int(rmax_schedule[j]))
 
 
+KRYLOVDIM_DEFAULT = 30          # KrylovKit.KrylovDefaults.krylovdim (third party; compat 0.6.1 / 0.9 / 0.10)
+
+
 def cg_solve(apply_K, rhs: np.ndarray, x0: np.ndarray, tol: float, maxiter: int):
     """Conjugate gradients as KrylovKit's `linsolve(f, b, x0; issymmetric = true, isposdef = true, tol, maxiter)` runs them (the
     call at src/solvers/dmrg.jl:170; KrylovKit is a third-party dependency, compat 0.6.1 / 0.9 / 0.10, not in the reference tree —
@@ -1047,7 +1050,10 @@ def dmrg_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1
             if V0 is None:                                              # b_mid(tt_opt, 1, 2)
                 V0 = np.reshape(np.einsum("ajg,kgb->ajkb", np.transpose(x.ttv_vec[i], (1, 0, 2)), x.ttv_vec[i + 1]), kd, order="F")
             assert V0.shape == kd, (V0.shape, kd)
-            v, iters = cg_solve(apply_K, np.reshape(Pb, N, order="F"), np.reshape(V0, N, order="F").copy(), linsolv_tol, linsolv_maxiter)
+            # KrylovKit's algorithm selector turns `maxiter` into CG(maxiter = krylovdim * maxiter) for isposdef problems, with
+            # krylovdim = KrylovDefaults.krylovdim = 30 (the convention src/solvers/euler.jl:29 spells out)
+            v, iters = cg_solve(apply_K, np.reshape(Pb, N, order="F"), np.reshape(V0, N, order="F").copy(), linsolv_tol,
+                                KRYLOVDIM_DEFAULT * linsolv_maxiter)
             if stats is not None:
                 stats["cg_iterations"] = stats.get("cg_iterations", 0) + iters
                 stats["cg_solves"] = stats.get("cg_solves", 0) + 1

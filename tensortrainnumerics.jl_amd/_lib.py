@@ -56,6 +56,7 @@ SIGNATURES = {
     "ttn_apply": (C.c_int, [handle, handle, handle]),
     "ttn_compress": (C.c_int, [handle, i64, C.c_double, i64]),
     "ttn_compress_status": (C.c_int, [handle, p_i64]),
+    "ttn_status_all": (C.c_int, []),
     "ttn_compress_rank_bound": (C.c_int, [i64, p_i64, p_i64, i64, i64, i64, p_i64, p_i64]),
     "ttn_bond_truncate": (C.c_int, [handle, i64, i64, C.c_double]),
     "ttn_apply_compress": (C.c_int, [handle, handle, handle, i64, C.c_double, i64]),

@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
         const long long* xr = P.x.rks + (long long)b * (d + 1);
         bool bad = false;
         for (int k = 0; k <= d; ++k) bad |= (xr[k] != P.rfix[k]);
-        if (bad) { if (tid == 0) P.status[b] = 4; return; }
+        if (bad) { if (tid == 0) ttn_set_status(&P.status[b], 4); return; }
     }
     const long long* br_ = P.b.rks + (long long)b * (d + 1);
     AlsEnv E;
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
             update_H(i);
         }
     }
-    if (!ok && tid == 0) P.status[b] = 3;
+    if (!ok && tid == 0) ttn_set_status(&P.status[b], 3);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(TTN_WG) k_mals_linsolve(MalsArgs Q) {
         if (dir == 0) als_update_G(E, i);
         else if (i > 0) update_H(i);
     }
-    if (status && tid == 0) P.status[b] = status;
+    if (status && tid == 0) ttn_set_status(&P.status[b], status);
 }
 #undef XC
 #undef BC

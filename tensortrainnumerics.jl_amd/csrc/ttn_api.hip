@@ -15,6 +15,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,8 @@ int ttn_wg512_selftest_gemm(int m, int n, int k, double* A, double* B, double* C
 // ------------------------------------------------------------------------------------------------
 namespace {
 int* g_next_train = nullptr;  // train counter of the persistent k_compress grid
+int* g_pending_status = nullptr;   // failure codes of handles that were FREED before anybody queried them (ttn_status_all)
+std::set<struct ttn_tt_s*> g_live;  // every live ttn_tt handle (ttn_status_all walks them)
 std::recursive_mutex g_mu;
 bool g_init = false;
 int g_device = -1;
@@ -129,6 +132,13 @@ struct ttn_tto_s {
 
 static bool same_dims(const std::vector<int64_t>& a, const std::vector<int64_t>& b) { return a == b; }
 
+// ttn_tt_free: the largest failure code still recorded on the dying handle moves to the library-level word
+__global__ void k_fold_status(const int* status, int batch, int* pending) {
+    int m = 0;
+    for (int b = threadIdx.x; b < batch; b += 64) m = max(m, status[b]);
+    if (m) atomicMax(pending, m);
+}
+
 extern "C" {
 
 const char* ttn_version(void) { return "ttn-mi355x 0.1.0 (gfx950, fp64)"; }
@@ -179,6 +189,8 @@ int ttn_init(int device) {
     static_assert(sizeof(CompressArgs) > 0, "");
     if (ttn_wg512_compress_args_bytes() != sizeof(CompressArgs)) return fail(TTN_ERR_ARG, "ttn_init: the two kernel builds disagree on CompressArgs");
     HIPCHK(hipMalloc((void**)&g_next_train, sizeof(int)));
+    HIPCHK(hipMalloc((void**)&g_pending_status, sizeof(int)));
+    HIPCHK(hipMemset(g_pending_status, 0, sizeof(int)));
     g_device = device;
     g_init = true;
     return TTN_OK;
@@ -191,7 +203,8 @@ int ttn_finalize(void) {
     if (g_scratch) hipFree(g_scratch);
     if (g_dout) hipFree(g_dout);
     if (g_next_train) hipFree(g_next_train);
-    g_next_train = nullptr;
+    if (g_pending_status) hipFree(g_pending_status);
+    g_next_train = nullptr; g_pending_status = nullptr;
     g_scratch = nullptr; g_scratch_bytes = 0; g_dout = nullptr; g_dout_cap = 0;
     hipEventDestroy(g_ev0); hipEventDestroy(g_ev1);
     for (auto e : g_slots) if (e) hipEventDestroy(e);
@@ -312,6 +325,7 @@ int ttn_tt_create(int64_t d, const int64_t* dims, const int64_t* cap_rks, int64_
     HIPCHK(hipMemsetAsync(h->d_data, 0, sizeof(double) * (size_t)o * batch, g_stream));
     HIPCHK(hipMemsetAsync(h->d_status, 0, sizeof(int) * 2 * (size_t)batch, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
+    g_live.insert(h);
     *out = h;
     return TTN_OK;
 }
@@ -319,6 +333,11 @@ int ttn_tt_create(int64_t d, const int64_t* dims, const int64_t* cap_rks, int64_
 int ttn_tt_free(ttn_tt_t h) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!h) return TTN_OK;
+    const bool was_live = g_live.erase(h) > 0;
+    if (g_init && was_live && h->d_status && g_pending_status) {
+        // a failure recorded on this handle that nobody has queried survives the handle (ttn_status_all)
+        hipLaunchKernelGGL(k_fold_status, dim3(1), dim3(64), 0, g_stream, (const int*)h->d_status, h->batch, g_pending_status);
+    }
     if (g_init) hipStreamSynchronize(g_stream);
     if (h->d_data) hipFree(h->d_data);
     if (h->d_off) hipFree(h->d_off);
@@ -504,6 +523,9 @@ static dim3 stream_grid(long long max_items, int d, int batch) {
     return dim3((unsigned)gx, (unsigned)d, (unsigned)batch);
 }
 
+// k_apply / k_hadamard / k_add count the fibres (p, q) of a core with 32-bit indices (ttn_stream_kernels.h): refuse larger cores here
+static bool stream_fibres_too_many(long long fibres) { return fibres >= (1LL << 31); }
+
 int ttn_apply(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     NEED_INIT();
@@ -515,6 +537,8 @@ int ttn_apply(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y) {
     long long maxfib = 0;
     for (int m = 0; m <= d; ++m) if (y->cap[m] < A->rks[m] * x->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_apply: destination capacity too small");
     for (int k = 0; k < d; ++k) maxfib = std::max<long long>(maxfib, (long long)x->bound[k] * x->bound[k + 1]);
+    if (stream_fibres_too_many(maxfib * std::max<long long>(1, A->rks[0]))) return fail(TTN_ERR_UNSUPPORTED, "ttn_apply: 2^31 or more fibres in one core (32-bit element indices)");
+    for (int k = 0; k < d; ++k) if (stream_fibres_too_many((long long)y->cap[k] * y->cap[k + 1])) return fail(TTN_ERR_UNSUPPORTED, "ttn_apply: 2^31 or more fibres in one output core (32-bit element indices)");
     hipLaunchKernelGGL(k_ranks_mul_op, dim3(x->batch), dim3(64), 0, g_stream, y->dev(), A->dev(), x->dev());
     // LDS of k_apply: the largest operator core (if it fits TTN_APPLY_LDS_DOUBLES) + the store-transpose buffer for the largest left rank
     long long amax_ = 0, rlmax_ = 1;
@@ -540,6 +564,7 @@ int ttn_hadamard(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z) {
     long long maxpq = 0;
     for (int m = 0; m <= d; ++m) if (z->cap[m] < x->bound[m] * y->bound[m]) return fail(TTN_ERR_CAPACITY, "ttn_hadamard: destination capacity too small");
     for (int k = 0; k < d; ++k) maxpq = std::max<long long>(maxpq, (long long)x->bound[k] * y->bound[k] * x->bound[k + 1] * y->bound[k + 1]);
+    if (stream_fibres_too_many(maxpq)) return fail(TTN_ERR_UNSUPPORTED, "ttn_hadamard: 2^31 or more fibres in one core (32-bit element indices)");
     hipLaunchKernelGGL(k_ranks_mul, dim3(x->batch), dim3(64), 0, g_stream, z->dev(), x->dev(), y->dev());
     hipLaunchKernelGGL(k_hadamard, stream_grid(maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), z->dev());
     HIPCHK(hipGetLastError());
@@ -562,6 +587,7 @@ int ttn_add(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z) {
     long long maxpq = 0;
     for (int m = 0; m <= d; ++m) if (z->cap[m] < zb[m]) return fail(TTN_ERR_CAPACITY, "ttn_add: destination capacity too small");
     for (int k = 0; k < d; ++k) maxpq = std::max<long long>(maxpq, (long long)zb[k] * zb[k + 1]);
+    if (stream_fibres_too_many(maxpq)) return fail(TTN_ERR_UNSUPPORTED, "ttn_add: 2^31 or more fibres in one core (32-bit element indices)");
     hipLaunchKernelGGL(k_ranks_add, dim3(x->batch), dim3(64), 0, g_stream, z->dev(), x->dev(), y->dev());
     hipLaunchKernelGGL(k_add, stream_grid(maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), z->dev());
     HIPCHK(hipGetLastError());
@@ -1195,6 +1221,7 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
 // has more than `itslv_thresh` unknowns, dense LU otherwise.  The dense path holds K in memory and is limited to TTN_DENSE_LOCAL_MAX
 // unknowns; larger systems always take the matrix-free path.
 #define TTN_DENSE_LOCAL_MAX 2048
+#define TTN_KRYLOVDIM_DEFAULT 30       // KrylovKit.KrylovDefaults.krylovdim
 struct LocalSolver { int it_solver = 0; int64_t itslv_thresh = TTN_DENSE_LOCAL_MAX; int64_t maxiter = 200; double tol = 1.0e-8; };
 static std::vector<int> g_cg_iters_host;       // total CG iterations per train of the last two-site solve (ttn_dmrg_cg_iterations)
 
@@ -1249,7 +1276,9 @@ static int two_site_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, d
     if (need_cg) { Q.offCg = cur; Q.cg_nmax = Nmax; cur += (4 + Rzmax) * Nmax; }
     Q.cg_all = ls.it_solver ? 1 : 0;
     Q.cg_above = (int)std::min<long long>(dense_max, (1LL << 30));
-    Q.cg_maxiter = (int)std::min<int64_t>(ls.maxiter, 1 << 30);
+    // KrylovKit's linsolve selector builds CG(maxiter = krylovdim * maxiter) for isposdef problems, krylovdim = KrylovDefaults' 30
+    // (the convention src/solvers/euler.jl:29 spells out; the call at src/solvers/dmrg.jl:170 passes maxiter = linsolv_maxiter only)
+    Q.cg_maxiter = (int)std::min<int64_t>(TTN_KRYLOVDIM_DEFAULT * ls.maxiter, 1 << 30);
     Q.cg_tol = ls.tol;
     P.offPb = cur; cur += Nmax;
     P.offPiv = cur; cur += Nmax / 2 + 8;
@@ -1373,6 +1402,27 @@ static int check_status(ttn_tt_t h) {
     for (int b = 0; b < batch; ++b) if (st[b] == 2) return fail(TTN_ERR_CAPACITY, "a rank grew beyond the rank capacity of its handle / working slot (site-swap chain or ttv_decomp)");
     for (int b = 0; b < batch; ++b) if (st[b]) return fail(TTN_ERR_NO_CONVERGENCE, "Jacobi SVD hit its sweep limit");
     return TTN_OK;
+}
+
+static int status_code_to_error(int st) {
+    if (st == 3) return fail(TTN_ERR_SINGULAR, "als_linsolve: a local system K is singular");
+    if (st == 4) return fail(TTN_ERR_DIMS, "als_linsolve: a train's ranks differ from the ranks of the start handle");
+    if (st == 2) return fail(TTN_ERR_CAPACITY, "a rank grew beyond the rank capacity of its handle / working slot (site-swap chain or ttv_decomp)");
+    if (st) return fail(TTN_ERR_NO_CONVERGENCE, "Jacobi SVD hit its sweep limit");
+    return TTN_OK;
+}
+
+int ttn_status_all(void) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    int st = 0;
+    for (ttn_tt_s* h : g_live)
+        if (h->d_status) hipLaunchKernelGGL(k_fold_status, dim3(1), dim3(64), 0, g_stream, (const int*)h->d_status, h->batch, g_pending_status);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&st, g_pending_status, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemsetAsync(g_pending_status, 0, sizeof(int), g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return status_code_to_error(st);
 }
 
 int ttn_compress_status(ttn_tt_t psi, int64_t* total_jacobi_sweeps) {

@@ -75,3 +75,7 @@ __host__ __device__ inline Idx plain(long long stride) { return Idx{0, stride, 0
 __host__ __device__ inline View tview(View v) { return View{v.p, v.c, v.r}; }
 __host__ __device__ inline View mkview(double* p, Idx r, Idx c) { return View{p, r, c}; }
 __host__ __device__ inline long long minstride(const Idx& d) { return d.q ? (d.lo < d.hi ? d.lo : d.hi) : d.lo; }
+
+// Per-train failure code of a handle (include/ttn.h: ttn_compress_status): the FIRST condition a train meets is kept — only the
+// workgroup that owns train b writes status[b], so a plain test is enough.
+__device__ inline void ttn_set_status(int* st, int code) { if (*st == 0) *st = code; }

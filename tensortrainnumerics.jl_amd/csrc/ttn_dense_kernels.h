@@ -3219,7 +3219,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
                 nsw = uni32(wg_svd_cols(P, S, p, X, ldx, x_in_lds));
                 nsw_total += (nsw < 0 ? -nsw : nsw);
                 if (attempt == 1) ok = nsw > 0;
-                else if (nsw < 0 && tid == 0) P.status[b] = 1;
+                else if (nsw < 0 && tid == 0) ttn_set_status(&P.status[b], 1);
             }
             PROF_MARK(3)
             if (!ok) continue;
@@ -3227,7 +3227,7 @@ __device__ __forceinline__ void wg_bond_step_io(const CompressArgs& P, int b, co
             const int r = wg_rank_rule(P, S, p, p, s0);
             FINE_MARK(21)
             if (SWAP != 0 && r > io.cap) {                                  // would not fit the slots: report, write nothing
-                if (tid == 0) { P.status[b] = 2; *io.rank_out = -1; }
+                if (tid == 0) { ttn_set_status(&P.status[b], 2); *io.rank_out = -1; }
                 __syncthreads();
                 done = true;
                 continue;
@@ -3554,7 +3554,7 @@ __global__ void TTN_KERNEL_BOUNDS k_swap_chain(ChainArgs Q) {
             for (int k = 0; k < d; ++k) {
                 const int sl = Q.final_slots[k];
                 const int rl = uni32((int)srl[sl]), rr = uni32((int)srr[sl]);
-                if (rl > Q.z.cap[k] || rr > Q.z.cap[k + 1]) { if (tid == 0) P.status[b] = 2; alive = false; break; }
+                if (rl > Q.z.cap[k] || rr > Q.z.cap[k + 1]) { if (tid == 0) ttn_set_status(&P.status[b], 2); alive = false; break; }
                 const double* src = Q.arena + (long long)b * Q.arena_stride + (long long)sl * Q.slot_doubles;
                 double* dst = Q.z.data + (long long)b * Q.z.stride + Q.z.off[k];
                 for (int e = tid; e < n * rl * rr; e += TTN_WG) dst[e] = src[e];

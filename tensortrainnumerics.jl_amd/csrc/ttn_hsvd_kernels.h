@@ -63,7 +63,7 @@ __device__ __noinline__ int wg_hsvd_step(const CompressArgs& P, int b, const Bon
     }
     __syncthreads();
     const int nsw = uni32(wg_svd_cols(P, S, p, X, ldx, x_in_lds));
-    if (tid == 0) { P.sweep_stats[b] += (nsw < 0 ? -nsw : nsw); if (nsw < 0) P.status[b] = 1; }
+    if (tid == 0) { P.sweep_stats[b] += (nsw < 0 ? -nsw : nsw); if (nsw < 0) ttn_set_status(&P.status[b], 1); }
     // rank: count(s >= tol), absolute (src/tt_tools.jl:203, :224); an all-zero remainder keeps one (zero) direction
     if (tid == 0) {
         int r = 0;
@@ -209,5 +209,5 @@ __global__ void __launch_bounds__(TTN_WG) k_ttv_decomp(HsvdArgs H) {
             const int al = (int)(t2 % rleft), be = (int)(t2 / rleft);
             core[e] = cur[(al + (long long)rleft * x) + (long long)rleft * n * be];
         }
-    } else if (tid == 0) P.status[b] = 2;
+    } else if (tid == 0) ttn_set_status(&P.status[b], 2);
 }

@@ -139,6 +139,12 @@ def compress_status(psi: DeviceTT) -> List[int]:
     return [int(v) for v in out]
 
 
+def status_all() -> None:
+    """Raises if any live handle, or a handle freed since the last query, carries a failure code (ttn_status_all): the ONE
+    check (one stream sync) a chain of asynchronous ops needs per time step / iteration."""
+    _lib.check(_lib.lib().ttn_status_all())
+
+
 def dot(a: DeviceTT, b: DeviceTT) -> np.ndarray:
     out = (C.c_double * a.batch)()
     _lib.check(_lib.lib().ttn_dot(a.h, b.h, out))

@@ -64,6 +64,7 @@ class DeviceBackend:
         # never blocks between a sweep and the send that follows it
         self.lib_stream = torch.cuda.ExternalStream(h.value)
         self._keep = []                            # tensors the library stream still reads (released at flush)
+        self._export_bufs = {}                     # (batch, doubles per train) -> persistent (core data, ranks) device buffers
 
     def prepare(self, A_cores, A_rks, x_trains, dims):
         """Upload the extended segment of the operator and of a micro-batch of trains (list of per-train core lists);
@@ -104,12 +105,20 @@ class DeviceBackend:
         import ctypes as C
         n, bl, br = C.c_int64(), C.c_int64(), C.c_int64()
         self._lib.check(self._lib.lib().ttn_tt_core_extent(seg.h, k + 1, C.byref(n), C.byref(bl), C.byref(br)))
-        dev = self.torch.device("cuda", self.torch.cuda.current_device())
-        data = self.torch.empty((seg.batch, n.value), dtype=self.torch.float64, device=dev)
-        rks = self.torch.empty((seg.batch, 2), dtype=self.torch.int64, device=dev)
+        # persistent export buffers, one pair per (batch, row length): no allocation per hand-off
+        key = (seg.batch, int(n.value))
+        bufs = self._export_bufs.get(key)
+        if bufs is None:
+            dev = self.torch.device("cuda", self.torch.cuda.current_device())
+            bufs = (self.torch.empty((seg.batch, n.value), dtype=self.torch.float64, device=dev),
+                    self.torch.empty((seg.batch, 2), dtype=self.torch.int64, device=dev))
+            self._export_bufs[key] = bufs
+        data, rks = bufs
+        # the library's stream writes these buffers: whatever torch's stream still does with them (the copy of the PREVIOUS
+        # export into its message) must be done first — and whatever the transport does next waits for the export.  Both are
+        # device-side event waits; the host goes on.
+        self.lib_stream.wait_stream(self.torch.cuda.current_stream())
         self._lib.check(self._lib.lib().ttn_tt_core_export(seg.h, k + 1, data.data_ptr(), rks.data_ptr()))
-        # the copy runs on the library's stream; whatever the transport does with the tensors on torch's stream waits for it
-        # on the DEVICE (an event), the host goes on
         self.torch.cuda.current_stream().wait_stream(self.lib_stream)
         return data, rks, int(bl.value), int(br.value)
 
@@ -120,6 +129,11 @@ class DeviceBackend:
         self.lib_stream.wait_stream(self.torch.cuda.current_stream())        # the received / copied tensors are ready before the import reads them
         self._lib.check(self._lib.lib().ttn_tt_core_import(seg.h, k + 1, data.data_ptr(), rks.data_ptr(), int(bl), int(br)))
         self._keep.append((data, rks))             # alive until the library stream has consumed them (release())
+
+    def fence(self):
+        """torch's current stream waits (on the device) for everything enqueued on the library's stream so far: called before a
+        persistent receive buffer that an earlier import read is handed to the transport again."""
+        self.torch.cuda.current_stream().wait_stream(self.lib_stream)
 
     def release(self):
         """Host sync point at the end of a sharded op: the tensors handed to the library may be freed afterwards."""
@@ -153,33 +167,84 @@ class DistTransport:
     Sender and receiver agree on the message size without a header: the extents (BL, BR) of the core are upper bounds both
     sides derive from what they hold — the rank capacities of the core's slot and max_bond (handoff_extents).  Message =
     [batch x n*BL*BR doubles: every train's core, compact with its current ranks at the start of its row | batch x 2: the
-    two ranks, as float64 (exact below 2^53)]."""
+    two ranks, as float64 (exact below 2^53)].
+
+    Buffers are PERSISTENT: per (peer, message length) a ring of RING message buffers on each side, reused round-robin — a send
+    buffer is reused once the send that last used it has completed, a receive buffer once its contents have been imported.
+    Receives can be PRE-POSTED (post_recv) so that the hand-off of micro-batch m+1 is already in flight while micro-batch m is
+    being swept; recv() posts the receive itself if nobody did.  Per pair of neighbours the order of operations is the same on
+    both sides (all L->R hand-offs in micro-batch order, then all R->L hand-offs), which RCCL's in-order point-to-point
+    matching requires: receives are therefore never posted across the direction change."""
+
+    RING = 2
 
     def __init__(self, dist, device="cpu"):
         import torch
         self.dist, self.torch, self.device = dist, torch, torch.device(device)
-        self._pending = []                         # (request, tensor) of sends in flight: the tensors must stay alive
+        self._send_ring = {}                       # (dst, numel) -> {"bufs": [...], "reqs": [...], "next": i}
+        self._recv_ring = {}                       # (src, numel) -> {"bufs": [...], "next": i}
+        self._stage = {}                           # (numel, device) -> staging buffer on the data's device (host transports)
+        self._posted = {}                          # (src, tag) -> (request, buffer, B, W)
+
+    def _ring(self, table, key, numel, with_reqs):
+        ring = table.get(key)
+        if ring is None:
+            ring = {"bufs": [self.torch.zeros(numel, dtype=self.torch.float64, device=self.device) for _ in range(self.RING)], "next": 0}
+            if with_reqs:
+                ring["reqs"] = [None] * self.RING
+            table[key] = ring
+        return ring
 
     def send(self, payload, dst: int, n: int, BL: int, BR: int):
         """Non-blocking: the sender goes on with its next micro-batch while the neighbour is still busy."""
         data, rks, bl, br = payload
         assert bl <= BL and br <= BR, (bl, br, BL, BR)
         B, W = data.shape[0], n * BL * BR
-        msg = self.torch.zeros(B * (W + 2), dtype=self.torch.float64, device=data.device)
+        numel = B * (W + 2)
+        ring = self._ring(self._send_ring, (dst, numel), numel, True)
+        i = ring["next"]
+        ring["next"] = (i + 1) % self.RING
+        if ring["reqs"][i] is not None:
+            ring["reqs"][i].wait()                 # the send that last used this buffer (RING hand-offs ago) has completed
+        out = ring["bufs"][i]
+        if data.device == out.device:
+            msg = out
+        else:                                      # host transport (gloo): pack on the data's device, one copy to the host buffer
+            skey = (numel, str(data.device))
+            msg = self._stage.get(skey)
+            if msg is None:
+                msg = self._stage[skey] = self.torch.zeros(numel, dtype=self.torch.float64, device=data.device)
         msg[: B * W].view(B, W)[:, : data.shape[1]] = data
         msg[B * W:].view(B, 2).copy_(rks.to(self.torch.float64))
-        t = msg.to(self.device)
-        self._pending.append((self.dist.isend(t, dst), t))
+        if msg is not out:
+            out.copy_(msg)
+        ring["reqs"][i] = self.dist.isend(out, dst)
 
     def flush(self):
-        for req, _ in self._pending:
-            req.wait()
-        self._pending = []
+        for ring in self._send_ring.values():
+            for i, req in enumerate(ring["reqs"]):
+                if req is not None:
+                    req.wait()
+                    ring["reqs"][i] = None
+        assert not self._posted, "a pre-posted receive was never consumed"
 
-    def recv(self, src: int, B: int, n: int, BL: int, BR: int):
+    def post_recv(self, src: int, B: int, n: int, BL: int, BR: int, tag):
+        """Start receiving the hand-off `tag` (any hashable: direction and micro-batch index) from `src` into the next buffer of
+        the ring.  The caller guarantees that the buffer's previous contents have been consumed (DeviceBackend.fence)."""
         W = n * BL * BR
-        msg = self.torch.empty(B * (W + 2), dtype=self.torch.float64, device=self.device)
-        self.dist.recv(msg, src)
+        numel = B * (W + 2)
+        ring = self._ring(self._recv_ring, (src, numel), numel, False)
+        i = ring["next"]
+        ring["next"] = (i + 1) % self.RING
+        buf = ring["bufs"][i]
+        self._posted[(src, tag)] = (self.dist.irecv(buf, src), buf, B, W)
+
+    def recv(self, src: int, B: int, n: int, BL: int, BR: int, tag=None):
+        if (src, tag) not in self._posted:
+            self.post_recv(src, B, n, BL, BR, tag)
+        req, msg, B_, W = self._posted.pop((src, tag))
+        assert (B_, W) == (B, n * BL * BR), "hand-off size mismatch between the pre-posted receive and its use"
+        req.wait()
         return msg[: B * W].view(B, W), msg[B * W:].view(B, 2).to(self.torch.int64), BL, BR
 
 
@@ -208,23 +273,41 @@ def sharded_apply_compress(backend, transport, rank: int, world: int, prepared: 
     micro-batches at the same time (pipeline, (world-1) stages of fill and drain per direction)."""
     segs = [backend.apply_prepared(p) for p in prepared]
     first, last = rank == 0, rank == world - 1
-    B, n0, nl = backend.batch(segs[0]), backend.phys_dim(segs[0], 0), backend.phys_dim(segs[0], n_ext - 1)
-    cap0, capl = backend.core_capacity(segs[0], 0), backend.core_capacity(segs[0], n_ext - 1)
+    fence = getattr(backend, "fence", lambda: None)
+
+    def shape(seg, k, direction):
+        """(batch, physical dimension, BL, BR) of the hand-off of core k of THIS micro-batch (micro-batches may differ in size)."""
+        return (backend.batch(seg), backend.phys_dim(seg, k)) + handoff_extents(*backend.core_capacity(seg, k), max_bond, direction)
+
+    M = len(segs)
     # ---- L -> R ----
-    for seg in segs:
+    if not first and M:
+        transport.post_recv(rank - 1, *shape(segs[0], 0, 0), tag=("lr", 0))
+    for m, seg in enumerate(segs):
         if not first:
-            backend.import_core(seg, 0, *transport.recv(rank - 1, B, n0, *handoff_extents(*cap0, max_bond, 0)))
+            got = transport.recv(rank - 1, *shape(seg, 0, 0), tag=("lr", m))
+            if m + 1 < M:                          # the next micro-batch's core travels while this one is swept
+                fence()
+                transport.post_recv(rank - 1, *shape(segs[m + 1], 0, 0), tag=("lr", m + 1))
+            backend.import_core(seg, 0, *got)
         backend.lr_sweep(seg, n_ext, max_bond, truncerr, not first)
         if not last:
-            transport.send(backend.export_core(seg, n_ext - 1), rank + 1, nl, *handoff_extents(*capl, max_bond, 0))
+            transport.send(backend.export_core(seg, n_ext - 1), rank + 1, *shape(seg, n_ext - 1, 0)[1:])
     # ---- R -> L ----
-    for seg in segs:
+    if not last and M:
+        fence()
+        transport.post_recv(rank + 1, *shape(segs[0], n_ext - 1, 1), tag=("rl", 0))
+    for m, seg in enumerate(segs):
         if not last:
-            backend.import_core(seg, n_ext - 1, *transport.recv(rank + 1, B, nl, *handoff_extents(*capl, max_bond, 1)))
+            got = transport.recv(rank + 1, *shape(seg, n_ext - 1, 1), tag=("rl", m))
+            if m + 1 < M:
+                fence()
+                transport.post_recv(rank + 1, *shape(segs[m + 1], n_ext - 1, 1), tag=("rl", m + 1))
+            backend.import_core(seg, n_ext - 1, *got)
         if n_ext >= 2:
             backend.sweep(seg, n_ext - 2, 0, max_bond, truncerr)
         if not first:
-            transport.send(backend.export_core(seg, 0), rank - 1, n0, *handoff_extents(*cap0, max_bond, 1))
+            transport.send(backend.export_core(seg, 0), rank - 1, *shape(seg, 0, 1)[1:])
     if transport is not None:
         transport.flush()
     backend.release()

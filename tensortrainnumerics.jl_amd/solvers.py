@@ -56,9 +56,8 @@ def _compress(x: DeviceTT, xr, max_bond: int):
         _lib.check(_lib.lib().ttn_tt_copy(big.h, x.h))
         x.free()
         x = big
-    D.tt_compress_(x, max_bond)
-    D.compress_status(x)        # a non-converged SVD inside a chain must not be committed silently (the codes are sticky per handle)
-    return x, fin
+    D.tt_compress_(x, max_bond)     # asynchronous: a failure code stays on the handle (or moves to the library word when the handle
+    return x, fin                   # is freed) until the chain's one check per time step / iteration (D.status_all)
 
 
 def _normalize(u: DeviceTT) -> None:
@@ -95,6 +94,7 @@ def rk4_method(A: DeviceTTO, u0: DeviceTT, steps: Sequence[float], max_bond: int
         if own:
             u.free()
         u, ur, own = un, unr, True
+        D.status_all()          # one check per time step: a non-converged SVD inside the step must not be committed silently
     return u
 
 
@@ -270,6 +270,7 @@ def _bicgstab(op, b: _Vec, x: _Vec, tol, maxiter: int, rr: int) -> _Vec:
         x = _vi_add(xa, s, omega, 1.0, rr); xa.free()
         rn = _vi_add(s, t, -omega, 1.0, rr); s.free(); t.free(); r.free(); r = rn
         rho = rho_new
+        D.status_all()                                        # one status check per Krylov iteration
     for w in (r, p, v, rhat_keep):
         if w is not None:
             w.free()
@@ -291,6 +292,7 @@ def _cg(op, b: _Vec, x: _Vec, tol, maxiter: int, rr: int) -> _Vec:
         rs_new = D.dot(r.h, r.h)
         pn = _vi_add(r, p, _safe_div(rs_new, rs), 1.0, rr); p.free(); p = pn
         rs = rs_new
+        D.status_all()                                        # one status check per Krylov iteration
     r.free(); p.free()
     return x
 
@@ -329,6 +331,7 @@ def _gmres(op, b: _Vec, x: _Vec, tol, krylovdim: int, maxiter: int, rr: int) -> 
             xn = _vi_add(x, V[j], ycoef[:, j], 1.0, rr); x.free(); x = xn
         for v in V:
             v.free()
+        D.status_all()                                        # one status check per restart cycle
     return x
 
 
@@ -354,6 +357,7 @@ def krylov_linsolve(A, b: DeviceTT, guess: DeviceTT, max_bond: int = 0, krylov_s
         x = _cg(op, bv, x, tol_value, krylovdim * maxiter, max_bond)                                                 # :28
     else:
         x = _gmres(op, bv, x, tol_value, krylovdim, maxiter, max_bond)
+    D.status_all()
     return x.h
 
 
@@ -379,6 +383,7 @@ def _implicit_stepper(A: TToperator, u0: DeviceTT, guess: DeviceTT, steps, norma
         if normalize:
             D.scale_batch(1.0 / D.norm(nxt), nxt, nxt)                                 # next / norm(next)
         v = _round(_Vec(nxt, _ranks_of(nxt)), max_bond)                               # tt_compress!(next, max_bond) : orthogonalize(next)
+        D.status_all()
         if own:
             sol.free()
         sol, own, guess = v.h, True, v.h
@@ -488,16 +493,21 @@ def dmrg_cg_iterations(batch: int):
 
 def dmrg_capacity(dims, start_rks, rmax: int, dense_only: bool = False):
     """Rank capacity of the result handle of dmrg_linsolve: the reference's buffer bounds min(rmax, prod(dims[:k]), prod(dims[k:]))
-    (dmrg.jl:411), at least the start ranks; the SVD core moves take n_i * rank up to 256.  dense_only: lowered until every
-    two-site system fits the dense solver (2048 unknowns) like mals_capacity."""
+    (dmrg.jl:411), at least the start ranks, clamped to what the SVD core moves take (n_i * rank <= 256: ranks saturate there
+    instead of growing to rmax; only START ranks beyond it are refused).  dense_only: lowered until every two-site system fits
+    the dense solver (2048 unknowns) like mals_capacity."""
     if dense_only:
         return mals_capacity(dims, start_rks, rmax)
     d = len(dims)
-    cap = [1] + [max(min(int(rmax), int(math.prod(dims[:k])), int(math.prod(dims[k:]))), int(start_rks[k])) for k in range(1, d)] + [1]
-    for k in range(d):
-        if dims[k] * max(cap[k], cap[k + 1]) > 256:
-            raise _lib.TTNError("dmrg_linsolve: n_k * rank above 256 is not supported (ranks up to 128 for n = 2)")
-    return cap
+    cap = [1]
+    for k in range(1, d):
+        lim = 256 // max(int(dims[k - 1]), int(dims[k]))        # the device bound: n * rank <= 256 on both cores that share bond k
+        if int(start_rks[k]) > lim:
+            raise _lib.TTNError("dmrg_linsolve: a start rank with n_k * rank above 256 is not supported (ranks up to 128 for n = 2)")
+        # the reference's buffer bound, CLAMPED to the device bound (so the default rmax_schedule = isqrt(prod(dims)) — 4096 for the
+        # 24-site C5 problem — works: the ranks then saturate at 128 for n = 2, which is the documented rank limit of this backend)
+        cap.append(max(min(int(rmax), int(math.prod(dims[:k])), int(math.prod(dims[k:])), lim), int(start_rks[k])))
+    return cap + [1]
 
 
 def dmrg_linsolve(A: TToperator, b: TTvector, tt_start: TTvector, tol: float = 1.0e-12, sweep_schedule: Sequence[int] = (2,),

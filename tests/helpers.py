@@ -73,3 +73,73 @@ def sign_fix_compare(a, b):
             carry = sa
         worst = max(worst, float(np.max(np.abs(ca - cb)) / max(np.max(np.abs(cb)), 1e-300)))
     return worst
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Extended-precision arbiter for singular values (numpy.longdouble: 64-bit mantissa on x86, eps 1.1e-19).
+# Used where two fp64 SVDs (LAPACK gesdd in the oracle, Householder/Gram + Jacobi on the device) of the same
+# ill-conditioned matrix disagree at the 1e-12 sigma_1 level: neither can arbitrate, this can.
+# ------------------------------------------------------------------------------------------------------------------
+def _householder_r_ld(A):
+    """R factor (n x n, upper triangular) of the m x n longdouble matrix A, m >= n, by Householder reflections."""
+    A = np.array(A, dtype=np.longdouble)
+    m, n = A.shape
+    for j in range(n):
+        x = A[j:, j]
+        nx = np.sqrt(np.sum(x * x))
+        if nx == 0:
+            continue
+        alpha = -nx if x[0] >= 0 else nx
+        v = x.copy()
+        v[0] -= alpha
+        nv2 = np.sum(v * v)
+        if nv2 == 0:
+            continue
+        A[j:, j:] -= np.outer(v, (2 / nv2) * (v @ A[j:, j:]))
+    return np.triu(A[:n, :])
+
+
+def ext_svdvals_rows(N, sweeps_max=60):
+    """Singular values (descending, longdouble) of the p x q matrix N by one-sided Jacobi on its ROWS in longdouble:
+    round-robin ordering, p/2 disjoint row pairs rotated at once (vectorised)."""
+    X = np.array(N, dtype=np.longdouble)
+    p = X.shape[0]
+    if p % 2:
+        X = np.vstack([X, np.zeros((1, X.shape[1]), dtype=np.longdouble)])
+        p += 1
+    eps = np.finfo(np.longdouble).eps
+    idx = np.arange(p)
+    for _ in range(sweeps_max):
+        rotated = False
+        order = idx.copy()
+        for _round in range(p - 1):
+            a, b = order[: p // 2], order[p // 2:][::-1]
+            xa, xb = X[a], X[b]
+            al, be, ga = np.sum(xa * xa, axis=1), np.sum(xb * xb, axis=1), np.sum(xa * xb, axis=1)
+            act = np.abs(ga) > 16 * eps * np.sqrt(al * be)
+            act &= (al > 0) & (be > 0)
+            if np.any(act):
+                rotated = True
+                ga_s = np.where(act, ga, 1)
+                zeta = (be - al) / (2 * ga_s)
+                t = np.sign(zeta + (zeta == 0)) / (np.abs(zeta) + np.sqrt(1 + zeta * zeta))
+                c = 1 / np.sqrt(1 + t * t)
+                s = c * t
+                c = np.where(act, c, 1)[:, None]
+                s = np.where(act, s, 0)[:, None]
+                X[a], X[b] = c * xa - s * xb, s * xa + c * xb
+            order = np.concatenate([order[:1], order[-1:], order[1:-1]])
+        if not rotated:
+            break
+    return np.sort(np.sqrt(np.sum(X * X, axis=1)))[::-1]
+
+
+def ext_svdvals_product(A, B):
+    """Singular values of A @ B (A: m x k with m >= k, B: k x q) to longdouble accuracy: the product is never rounded to fp64 —
+    R = qr(A) in longdouble, then Jacobi on the k rows of R @ B."""
+    A = np.array(A, dtype=np.longdouble)
+    B = np.array(B, dtype=np.longdouble)
+    if A.shape[0] < A.shape[1]:
+        return ext_svdvals_rows(A @ B) if A.shape[0] <= B.shape[1] else ext_svdvals_rows((A @ B).T)
+    R = _householder_r_ld(A)
+    return ext_svdvals_rows(R @ B)

@@ -80,7 +80,8 @@ class OracleBackend:
         for b, cores in enumerate(seg):
             n = int(cores[k].shape[0])
             rl, rr = int(rks[b, 0]), int(rks[b, 1])
-            cores[k] = np.asfortranarray(data[b, : n * rl * rr].reshape((n, rl, rr), order="F"))
+            # a COPY: the transport's receive buffers are persistent and will be overwritten by a later hand-off
+            cores[k] = np.array(data[b, : n * rl * rr].reshape((n, rl, rr), order="F"), order="F", copy=True)
 
     def download(self, seg, b: int):
         return [np.array(c) for c in seg[b]]
