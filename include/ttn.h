@@ -216,6 +216,9 @@ int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, do
 
 /* out[b] = dot(a_b, b_b)      src/tt_operations.jl:239-250 ; out is HOST memory, length batch (synchronises) */
 int ttn_dot(ttn_tt_t a, ttn_tt_t b, double* out);
+/* HIP-event time of the KERNEL of the last ttn_dot / ttn_norm / ttn_orthogonalize call alone (ttn_dot itself goes on to copy the
+ * results to the host and synchronises, which an event pair around the call would include) — what bench.py --op reports */
+int ttn_last_launch_ms(float* ms);
 /* out[b] = norm(a_b) = sqrt(max(dot(a,a),0))   src/tt_operations.jl:465-470 */
 int ttn_norm(ttn_tt_t a, double* out);
 

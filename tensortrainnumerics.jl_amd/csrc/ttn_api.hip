@@ -3,6 +3,7 @@
 #include "ttn_common.h"
 #include "ttn_stream_kernels.h"
 #include "ttn_dense_kernels.h"
+#include "ttn_dot_kernels.h"
 #include "ttn_ortho_kernels.h"
 #include "ttn_hsvd_kernels.h"
 #include "ttn_als_kernels.h"
@@ -76,6 +77,14 @@ int ensure_scratch(size_t bytes) {
     }
     HIPCHK(hipMalloc(&g_scratch, bytes));
     g_scratch_bytes = bytes;
+    return TTN_OK;
+}
+bool g_have_launch_ms = false;     // g_ev0 / g_ev1 bracket the last ttn_dot / ttn_orthogonalize kernel (ttn_last_launch_ms)
+int ensure_prof(int batch) {        // TTN_PROF=1: 200 counters per train, zeroed
+    static int prof_cap = 0;
+    if (prof_cap < batch) { if (g_prof) hipFree(g_prof); g_prof = nullptr; HIPCHK(hipMalloc((void**)&g_prof, sizeof(long long) * 200 * batch)); prof_cap = batch; }
+    HIPCHK(hipMemsetAsync(g_prof, 0, sizeof(long long) * 200 * batch, g_stream));
+    g_prof_batch = batch;
     return TTN_OK;
 }
 int ensure_batch_bufs(int batch) {
@@ -176,8 +185,8 @@ int ttn_init(int device) {
                                (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_orthogonalize), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(ORTHO_LDS_BYTES)));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dot), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(double) * GEMM_LDS_TOTAL)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dot_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(DOT_LDS_BYTES(DOT_MAX_D))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_selftest_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(double) * GEMM_LDS_TOTAL)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -777,11 +786,8 @@ static int launch_compress(ttn_tt_t psi, int64_t k_single, int64_t max_bond, dou
     P.prof = nullptr;
     { const char* e = getenv("TTN_PROF_STEP"); P.prof_step = e ? atoi(e) : -1; }
     if (getenv("TTN_PROF")) {
-        static long long* d_prof = nullptr; static int prof_cap = 0;
-        if (prof_cap < psi->batch) { if (d_prof) hipFree(d_prof); HIPCHK(hipMalloc((void**)&d_prof, sizeof(long long) * 200 * psi->batch)); prof_cap = psi->batch; }
-        HIPCHK(hipMemsetAsync(d_prof, 0, sizeof(long long) * 200 * psi->batch, g_stream));
-        g_prof_batch = psi->batch;
-        P.prof = d_prof; g_prof = d_prof;
+        { int rcp = ensure_prof(psi->batch); if (rcp) return rcp; }
+        P.prof = g_prof;
     }
     { const char* e = getenv("TTN_JTOL"); P.jtol_mult = e ? atof(e) : 1.0; }
     { const char* e = getenv("TTN_JNEG"); P.jneg_mult = e ? atof(e) : 1.0; }
@@ -1478,6 +1484,8 @@ int ttn_dot(ttn_tt_t a, ttn_tt_t b, double* out) {
     if (!same_dims(a->dims, b->dims)) return fail(TTN_ERR_DIMS, "TT dimensions are not compatible");
     if (a->batch != b->batch) return fail(TTN_ERR_DIMS, "batch sizes differ");
     const int d = a->d;
+    if (d > DOT_MAX_D) return fail(TTN_ERR_UNSUPPORTED, "ttn_dot: chains longer than 480 sites are not supported");
+    if (a->stride >= (1LL << 31) || b->stride >= (1LL << 31)) return fail(TTN_ERR_UNSUPPORTED, "ttn_dot: a train of 2^31 doubles or more");
     long long ramax = 1, rbmax = 1, nmax = 1;
     for (int m = 0; m <= d; ++m) { ramax = std::max<long long>(ramax, a->bound[m]); rbmax = std::max<long long>(rbmax, b->bound[m]); }
     for (int k = 0; k < d; ++k) nmax = std::max<long long>(nmax, a->dims[k]);
@@ -1491,10 +1499,25 @@ int ttn_dot(ttn_tt_t a, ttn_tt_t b, double* out) {
     P.scratch = (double*)g_scratch; P.scratch_stride = per_train;
     P.ramax = (int)ramax; P.rbmax = (int)rbmax; P.nmax = (int)nmax;
     P.out = g_dout;
-    hipLaunchKernelGGL(k_dot, dim3(a->batch), dim3(TTN_WG), sizeof(double) * GEMM_LDS_TOTAL, g_stream, P);
+    P.prof = nullptr;
+    if (getenv("TTN_PROF")) { int rcp = ensure_prof(a->batch); if (rcp) return rcp; P.prof = g_prof; }
+    HIPCHK(hipEventRecord(g_ev0, g_stream));
+    hipLaunchKernelGGL(k_dot_fused, dim3(a->batch), dim3(TTN_WG), DOT_LDS_BYTES(d), g_stream, P);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(g_ev1, g_stream));              // ttn_last_launch_ms: the kernel alone (this call goes on to copy and synchronise)
+    g_have_launch_ms = true;
     HIPCHK(hipMemcpyAsync(out, g_dout, sizeof(double) * a->batch, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
+    return TTN_OK;
+}
+
+int ttn_last_launch_ms(float* ms) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!ms) return fail(TTN_ERR_ARG, "null pointer");
+    if (!g_have_launch_ms) return fail(TTN_ERR_ARG, "ttn_last_launch_ms: no ttn_dot / ttn_orthogonalize launch yet");
+    HIPCHK(hipEventSynchronize(g_ev1));
+    HIPCHK(hipEventElapsedTime(ms, g_ev0, g_ev1));
     return TTN_OK;
 }
 
@@ -1532,8 +1555,11 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     P.center = (int)center - 1;
     P.scratch = (double*)g_scratch; P.scratch_stride = per_train;
     P.mmax = (int)mm; P.rmax = (int)rmax;
+    HIPCHK(hipEventRecord(g_ev0, g_stream));
     hipLaunchKernelGGL(k_orthogonalize, dim3(x->batch), dim3(TTN_WG), ORTHO_LDS_BYTES, g_stream, P);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(g_ev1, g_stream));
+    g_have_launch_ms = true;
     y->bound = yb;
     for (int b = 0; b < y->batch; ++b)
         for (int k = 0; k < d; ++k) y->ot[(size_t)b * d + k] = (k < center - 1) ? 1 : (k > center - 1 ? -1 : 0);

@@ -3578,42 +3578,10 @@ struct DotArgs {
     long long scratch_stride;
     int ramax, rbmax, nmax;
     double* out;                // [batch] device
+    long long* prof;            // TTN_PROF=1: s_memtime stamp after every site of train b at prof[16 * batch + 120 * b + k] (ttn_prof_steps)
 };
 
-__global__ void TTN_KERNEL_BOUNDS k_dot(DotArgs P) {
-    extern __shared__ double lds[];
-    const int t = blockIdx.x;
-    const TTDev& A = P.a; const TTDev& B = P.b;
-    const long long* ar = A.rks + (long long)t * (A.d + 1);
-    const long long* br = B.rks + (long long)t * (B.d + 1);
-    double* scr = P.scratch + (long long)t * P.scratch_stride;
-    double* M0 = scr;
-    double* M1 = M0 + (long long)P.ramax * P.rbmax;
-    double* Tb = M1 + (long long)P.ramax * P.rbmax;
-    if (threadIdx.x == 0) M0[0] = 1.0;
-    __syncthreads();
-    double* Mc = M0; double* Mn = M1;
-    for (int k = 0; k < A.d; ++k) {
-        const int n = A.dims[k];
-        const int ra = uni32((int)ar[k]), ra2 = uni32((int)ar[k + 1]), rb = uni32((int)br[k]), rb2 = uni32((int)br[k + 1]);
-        double* Ak = A.data + (long long)t * A.stride + A.off[k];
-        double* Bk = B.data + (long long)t * B.stride + B.off[k];
-        // M (ra x rb) column-major: M[al + ra*be]
-        const View Mv = mkview(Mc, plain(1), plain(ra));
-        // B as [be, (z + n*b)] : offset z + n*be + n*rb*b
-        const View Bv = mkview(Bk, plain(n), Idx{n, 1, (long long)n * rb});
-        // T as [al, (z + n*b)] stored at z + n*al + n*ra*b  (so that (z,al) is a plain K index below)
-        const View Tv = mkview(Tb, plain(n), Idx{n, 1, (long long)n * ra});
-        wg_gemm(ra, n * rb2, rb, Mv, Bv, Tv, 1.0, 0.0, lds);
-        // A^T as [a, (z + n*al)] : offset (z + n*al) + n*ra*a ; T as [(z + n*al), b] : offset kk + n*ra*b
-        const View Atv = mkview(Ak, plain((long long)n * ra), plain(1));
-        const View T2v = mkview(Tb, plain(1), plain((long long)n * ra));
-        const View Mnv = mkview(Mn, plain(1), plain(ra2));
-        wg_gemm(ra2, rb2, n * ra, Atv, T2v, Mnv, 1.0, 0.0, lds);
-        double* tmp = Mc; Mc = Mn; Mn = tmp;
-    }
-    if (threadIdx.x == 0) P.out[t] = Mc[0];
-}
+// (the kernel: ttn_dot_kernels.h)
 
 // -------------------------------------------------------------------------------------------------
 // kernel unit-test hook for wg_gemm (tests/test_gpu_kernels.py): one workgroup, plain row-major operands

@@ -51,7 +51,7 @@ __device__ void dev_r_and_d_to_rks(int d, const int* dims, const long long* rks,
     }
 }
 
-__global__ void __launch_bounds__(TTN_WG) k_orthogonalize(OrthoArgs P) {
+__global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;

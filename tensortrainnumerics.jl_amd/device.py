@@ -184,6 +184,13 @@ def orthogonalize(x: DeviceTT, i: int, y: DeviceTT) -> DeviceTT:
     return y
 
 
+def last_launch_ms() -> float:
+    """HIP-event time of the kernel of the last dot / norm / orthogonalize call alone (ttn_last_launch_ms)."""
+    ms = C.c_float(0.0)
+    _lib.check(_lib.lib().ttn_last_launch_ms(C.byref(ms)))
+    return float(ms.value)
+
+
 def sync() -> None:
     _lib.check(_lib.lib().ttn_sync())
 

@@ -151,6 +151,29 @@ def test_dot_full_size_vs_oracle(T, d, ra, rb):
     assert math.isclose(T.norm(a), O.norm(to_oracle(a)), rel_tol=1e-12)
 
 
+@pytest.mark.parametrize("d,ra,rb,seed", [(9, 5, 13, 0), (12, 37, 64, 1), (14, 64, 21, 2), (30, 64, 64, 3), (7, 16, 17, 4), (2, 2, 2, 5)])
+def test_dot_lds_resident_path_odd_ranks(T, d, ra, rb, seed):
+    """The LDS-resident form of k_dot (n = 2, every rank <= 64; csrc/ttn_dot_kernels.h) on ranks that are NOT multiples of the 16 x 16
+    MFMA tile and differ between the two trains — masked fragments, partially filled tile grids, rank ramps at both ends — against
+    the oracle (src/tt_operations.jl:239-250) to 1e-12, plus a batch whose trains carry different ranks."""
+    rng = np.random.default_rng(100 + seed)
+    a = to_product(O.rand_tt((2,) * d, ra, rng))
+    b = to_product(O.rand_tt((2,) * d, rb, rng))
+    ref = O.dot(to_oracle(a), to_oracle(b))
+    scale = O.norm(to_oracle(a)) * O.norm(to_oracle(b))
+    assert abs(T.dot(a, b) - ref) <= 1e-12 * scale
+    assert abs(T.dot(b, a) - ref) <= 1e-12 * scale
+    # ragged batch: train 1 has smaller ranks than the handle's capacity
+    a2 = to_product(O.rand_tt((2,) * d, max(1, ra // 2), rng))
+    b2 = to_product(O.rand_tt((2,) * d, max(1, rb // 3), rng))
+    da, db = T.DeviceTT(a.ttv_dims, a.ttv_rks, batch=2), T.DeviceTT(b.ttv_dims, b.ttv_rks, batch=2)
+    da.upload(0, a); da.upload(1, a2); db.upload(0, b); db.upload(1, b2)
+    got = T.device.dot(da, db)
+    assert abs(got[0] - ref) <= 1e-12 * scale
+    ref2 = O.dot(to_oracle(a2), to_oracle(b2))
+    assert abs(got[1] - ref2) <= 1e-12 * O.norm(to_oracle(a2)) * O.norm(to_oracle(b2))
+
+
 def test_hadamard_closed_forms(T):
     d = 8                                   # test/test_tt_operations.jl:41-71
     x = np.linspace(0, 1, 2 ** d)
