@@ -11,8 +11,8 @@ run() {  # name, script + args
   cp $OUT/$name/s_kernel_stats.csv $ROOT/gpurun_out/${TAG}_${name}_kernel_stats.csv 2>/dev/null
   rm -rf $OUT/$name
 }
-run swap $ROOT/tests/diag_swap.py 20 4 4 256
-run hsvd $ROOT/tests/diag_hsvd.py
-run als $ROOT/tests/diag_als.py 8 16 64 2
+run swap $ROOT/tools/diag_swap.py 20 4 4 256
+run hsvd $ROOT/tools/diag_hsvd.py
+run als $ROOT/tools/diag_als.py 8 16 64 2
 cd $ROOT
 head -4 gpurun_out/${TAG}_*_kernel_stats.csv | cut -c1-160

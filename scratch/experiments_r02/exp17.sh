@@ -7,6 +7,6 @@ for i in 1 2 3 4 5 6; do rocm-smi --showclocks --showpower --showuse 2>&1 | grep
 wait $BP
 tail -1 gpurun_out/exp17_bench.json | cut -c1-200
 echo "== idle"; rocm-smi --showclocks --showpower 2>&1 | grep -E "sclk|Power" | head -4
-(TTN_WG512=0 python tests/diag_batch.py 1 > /dev/null 2>&1; for k in 1 2 3 4 5 6 7 8; do python - <<'PY'
+(TTN_WG512=0 python tools/diag_batch.py 1 > /dev/null 2>&1; for k in 1 2 3 4 5 6 7 8; do python - <<'PY'
 PY
 done) 

@@ -4,6 +4,6 @@ rm -f gpurun_out/exp22.raw
 run timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "fused or headline or apply_compress or bench_batch or randomized" || exit 1
 grep -q "failed" gpurun_out/exp22.raw && exit 1
 for i in 1 2 3; do run timeout -k 10 200 python bench.py --no-cpu --no-single --no-verify --steps 6 || exit 1; TTN_FAST=513 run timeout -k 10 200 python bench.py --no-cpu --no-single --no-verify --steps 6 || exit 1; done
-TTN_PROF_STEP=10 TTN_WG512=0 run python tests/diag_fine.py 1
-TTN_PROF_STEP=10 TTN_WG512=1 run python tests/diag_fine.py 512
-TTN_PROF=1 run timeout -k 10 120 python tests/diag_batch.py 1 || exit 1
+TTN_PROF_STEP=10 TTN_WG512=0 run python tools/diag_fine.py 1
+TTN_PROF_STEP=10 TTN_WG512=1 run python tools/diag_fine.py 512
+TTN_PROF=1 run timeout -k 10 120 python tools/diag_batch.py 1 || exit 1

@@ -6,5 +6,5 @@ grep -q "failed" gpurun_out/exp32.raw && exit 1
 run timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "headline or bench_batch or eigen" || exit 1
 grep -q "failed" gpurun_out/exp32.raw && exit 1
 run bash scratch/ab2.sh st1 st2
-TTN_PROF_STEP=10 run python tests/diag_fine.py 1
-TTN_LIB=$PWD/tensortrainnumerics.jl_amd/libttn_st1.so TTN_PROF_STEP=10 run python tests/diag_fine.py 1
+TTN_PROF_STEP=10 run python tools/diag_fine.py 1
+TTN_LIB=$PWD/tensortrainnumerics.jl_amd/libttn_st1.so TTN_PROF_STEP=10 run python tools/diag_fine.py 1

@@ -6,5 +6,5 @@ grep -q "failed" gpurun_out/exp33.raw && exit 1
 TTN_LIB=$PWD/tensortrainnumerics.jl_amd/libttn_s16.so run timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "golden or headline or bench_batch or randomized" || exit 1
 grep -q "failed" gpurun_out/exp33.raw && exit 1
 run bash scratch/ab2.sh base s8 s16
-TTN_LIB=$PWD/tensortrainnumerics.jl_amd/libttn_s16.so TTN_PROF=1 run python tests/diag_batch.py 1
-TTN_LIB=$PWD/tensortrainnumerics.jl_amd/libttn_s8.so TTN_PROF=1 run python tests/diag_batch.py 1
+TTN_LIB=$PWD/tensortrainnumerics.jl_amd/libttn_s16.so TTN_PROF=1 run python tools/diag_batch.py 1
+TTN_LIB=$PWD/tensortrainnumerics.jl_amd/libttn_s8.so TTN_PROF=1 run python tools/diag_batch.py 1

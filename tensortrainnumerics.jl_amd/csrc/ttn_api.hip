@@ -1545,7 +1545,8 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     for (int m = 0; m <= d; ++m) rmax = std::max<long long>(rmax, x->bound[m]);
     for (int k = 0; k < d; ++k) nmax = std::max<long long>(nmax, x->dims[k]);
     const long long mm = nmax * rmax;           // rows of the tall matrices
-    const long long per_train = 2 * mm * rmax + 4 * rmax * rmax + 2 * QR_NB * mm + ((rmax + QR_NB - 1) / QR_NB) * QR_NB * QR_NB + 64;   // Tm, Qb, 4 R, Vb, Wb, T panels
+    const long long per_train = 2 * mm * rmax + 4 * rmax * rmax + 2 * QR_NB * mm + ((rmax + QR_NB - 1) / QR_NB) * QR_NB * QR_NB + 64   // Tm, Qb, 4 R, Vb, Wb, T panels
+                                + 3 * 128 * 128;                                                                                  // Gram matrices / L1 of the Cholesky-QR steps
     int rc = ensure_scratch(sizeof(double) * (size_t)per_train * x->batch);
     if (rc) return rc;
     rc = ensure_batch_bufs(x->batch);
@@ -1555,6 +1556,9 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     P.center = (int)center - 1;
     P.scratch = (double*)g_scratch; P.scratch_stride = per_train;
     P.mmax = (int)mm; P.rmax = (int)rmax;
+    { const char* e = getenv("TTN_ORTHO_CHOLQR"); P.no_cholqr = e ? (atoi(e) == 0 ? 3 : (atoi(e) == 1 ? 2 : 0)) : 0; }
+    P.prof = nullptr;
+    if (getenv("TTN_PROF")) { int rcp = ensure_prof(x->batch); if (rcp) return rcp; P.prof = g_prof; }
     HIPCHK(hipEventRecord(g_ev0, g_stream));
     hipLaunchKernelGGL(k_orthogonalize, dim3(x->batch), dim3(TTN_WG), ORTHO_LDS_BYTES, g_stream, P);
     HIPCHK(hipGetLastError());

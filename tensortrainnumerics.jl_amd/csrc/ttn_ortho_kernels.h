@@ -3,6 +3,7 @@
 #pragma once
 #include "ttn_common.h"
 #include "ttn_dense_kernels.h"
+#include "ttn_ortho_fused.h"
 
 #define ORTHO_LDS_BYTES ((GEMM_LDS_TOTAL + 32 + 2 * QR_NB * QR_NB + 2 * QR_NB) * sizeof(double))
 
@@ -12,6 +13,9 @@ struct OrthoArgs {
     double* scratch;
     long long scratch_stride;
     int mmax, rmax;
+    int no_cholqr;              // bit 0: no Cholesky-QR steps on the general route, bit 1: no fused steps (TTN_ORTHO_CHOLQR = 0 sets both,
+                                // 1 only bit 1: diagnostics, parity tests of every route)
+    long long* prof;            // TTN_PROF=1: s_memtime stamp after every QR / LQ step of train b at prof[16 * batch + 120 * b + step] (ttn_prof_steps)
 };
 
 // Thin QR  T = Q R  of the column-major mm x nn matrix Tm (ld = mm) through the blocked Householder LQ of its
@@ -29,6 +33,60 @@ __device__ int wg_qr_explicit(int mm, int nn, double* Tm, double* Qb, double* Rb
     }
     __syncthreads();
     return rnew;
+}
+
+// The same factorisation by Cholesky-QR for tall, well-conditioned T with nn <= 64 columns (the interior sites of a rank-64 train:
+// cond(T) ~ 10 measured on the benchmark's random trains — the rank-ramp sites at both ends of a chain are square and reach 1e8, they
+// stay on the Householder route).  In the row-major view M = T^T (nn x mm, the storage of Tm read row by row):
+//   G = M M^T (MFMA, wg_syrk) -> L1 = chol(G) in LDS -> Q1 = L1^-1 M (forward substitution, one thread per column: backward stable,
+//   M = L1 Q1 + E with |E| <= eps |L1| |Q1|) -> C = Q1 Q1^T (MFMA): dev = max |C - I| ~ eps cond(T)^2 MEASURES the orthogonality.
+//   dev <= ORTHO_CHOLQR_ACCEPT: Q1 is the orthonormal factor (1e-12 is the parity bar of orthogonalize; 2.7e-15 at cond 10);
+//   dev <= ORTHO_CHOLQR_SECOND: second pass L2 = chol(C), Q = L2^-1 Q1, L = L1 L2 (CholeskyQR2, as the rank-ramp steps of k_compress);
+//   otherwise, or when a pivot fails: return 0 with Tm untouched — the caller runs the Householder route.
+// Against the in-LDS Householder LQ + explicit Q of round 2 (64 reflectors, each applied twice, one barrier per reflector and
+// pass: 446 k clk per 64 x 128 site) this is two Gram products, one 64 x 64 factorisation and one triangular solve.
+// Outputs as wg_qr_explicit: Qb (mm x nn column-major), Rb (nn x nn, ld = nn, zeros below the diagonal) — R has a positive diagonal.
+#define ORTHO_CHOLQR_ACCEPT 2.0e-13
+#define ORTHO_CHOLQR_SECOND 1.0e-6
+#define ORTHO_CHOLQR_PIVOT_MAX 1.0e8         // pivot ratio (a lower bound of cond^2) above which the attempt stops after the factorisation
+struct CholQrWork { double *Ga, *Cc, *L1g; double* scal; int* iflag; double* red; long long* stamps; };
+#define OQ_STAMP(i) if (Cw.stamps && threadIdx.x == 0) Cw.stamps[i] += (long long)__builtin_amdgcn_s_memtime() - t_prev_; if (Cw.stamps) t_prev_ = (long long)__builtin_amdgcn_s_memtime();
+__device__ __noinline__ int wg_qr_cholqr(int mm, int nn, double* Tm, double* Qb, double* Rb, CholQrWork Cw, double* lds) {
+    mm = uni32(mm); nn = uni32(nn); Tm = unip(Tm); Qb = unip(Qb); Rb = unip(Rb); lds = unip(lds);
+    Cw.Ga = unip(Cw.Ga); Cw.Cc = unip(Cw.Cc); Cw.L1g = unip(Cw.L1g); Cw.scal = unip(Cw.scal); Cw.iflag = unip(Cw.iflag); Cw.red = unip(Cw.red);
+    const int tid = threadIdx.x;
+    const int p = nn, q = mm;
+    long long t_prev_ = Cw.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    const View Mv = mkview(Tm, plain(q), plain(1));                          // M[i, c] = Tm[i * mm + c] = T[c, i]
+    wg_syrk(p, q, Mv, mkview(Cw.Ga, plain(1), plain(128)), 1.0, lds);
+    OQ_STAMP(0)
+    wg_img_load(lds, 0, Cw.Ga, p, Cw.red);
+    if (wg_chol_lds128(p, lds, Cw.red, Cw.iflag, Cw.scal + 1) != 0) return 0;
+    if (!(unif64(Cw.scal[1]) <= ORTHO_CHOLQR_PIVOT_MAX)) return 0;
+    for (int e = tid; e < p * p; e += TTN_WG) { const int i = e % p, j = e / p; Cw.L1g[i + 128 * j] = lds[i + 128 * j]; }      // L1 (the Gram product below takes the image)
+    OQ_STAMP(1)
+    wg_trsm_lower_cols(p, q, lds, Tm, q, 1.0, Qb, q);                        // Q1 = L1^-1 M, row-major p x q = Qb column-major mm x nn
+    OQ_STAMP(2)
+    wg_syrk(p, q, mkview(Qb, plain(q), plain(1)), mkview(Cw.Cc, plain(1), plain(128)), 1.0, lds);
+    const double dev = wg_img_load(lds, 0, Cw.Cc, p, Cw.red);
+    OQ_STAMP(3)
+    const double* Lsrc = Cw.L1g;                                             // L[i, k] at Lsrc[i + 128 k]
+    if (!(dev <= ORTHO_CHOLQR_ACCEPT)) {
+        if (!(dev <= ORTHO_CHOLQR_SECOND)) return 0;
+        if (wg_chol_lds128(p, lds, Cw.red, Cw.iflag, Cw.scal + 1) != 0) return 0;
+        wg_trsm_lower_cols(p, q, lds, Qb, q, 1.0, Qb, q);                    // Q = L2^-1 Q1 (in place: a thread owns its column)
+        wg_img_load(lds, 64, Cw.L1g, p, Cw.red);
+        wg_tril_mul_lds(p, lds);                                             // L = L1 L2 in the image
+        for (int e = tid; e < p * p; e += TTN_WG) { const int i = e % p, j = e / p; Cw.L1g[i + 128 * j] = lds[i + 128 * j]; }
+        __syncthreads();
+    }
+    for (int e = tid; e < p * p; e += TTN_WG) {                              // R = L^T: Rb[i + nn c] = L[c, i] for i <= c
+        const int i = e % p, c = e / p;
+        Rb[e] = (i <= c) ? Lsrc[c + 128 * i] : 0.0;
+    }
+    __syncthreads();
+    OQ_STAMP(4)
+    return p;
 }
 
 // device restatement of r_and_d_to_rks (src/tt_tools.jl:407-425) with Julia's wrapping Int64 products
@@ -75,6 +133,14 @@ __global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
     W.Ts = red + 32;
     W.Ss = W.Ts + QR_NB * QR_NB;
     W.taus = W.Ss + QR_NB * QR_NB;
+    CholQrWork Cw;                                                           // Cholesky-QR of the well-conditioned tall steps (rank <= 64)
+    Cw.Ga = W.Tst + (long long)((P.rmax + QR_NB - 1) / QR_NB) * QR_NB * QR_NB;
+    Cw.Cc = Cw.Ga + 128 * 128;
+    Cw.L1g = Cw.Cc + 128 * 128;
+    Cw.scal = W.Ss;                                                          // LDS words of the Householder panel matrices, dead outside wg_lq_blocked
+    Cw.iflag = (int*)(W.Ss + 8);
+    Cw.red = red;
+    Cw.stamps = P.prof ? P.prof + 136LL * gridDim.x + 64LL * b : nullptr;
     if (tid == 0) dev_r_and_d_to_rks(d, X.dims, xr, 1024, yr);
     __syncthreads();
     const int ic = P.center;
@@ -95,7 +161,8 @@ __global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
         const View Tv = mkview(Tm, plain(1), Idx{n, (long long)yl, (long long)mm});   // [al, (s + n*be)]
         wg_gemm(yl, n * rr, rl, FR, Xv, Tv, 1.0, 0.0, lds);
         double* Rn = which ? Rb0 : Rb1;
-        const int rnew = wg_qr_explicit(mm, rr, Tm, Qb, Rn, W, lds);
+        int rnew = (rr <= 64 && mm > rr && !(P.no_cholqr & 1)) ? wg_qr_cholqr(mm, rr, Tm, Qb, Rn, Cw, lds) : 0;
+        if (!rnew) rnew = wg_qr_explicit(mm, rr, Tm, Qb, Rn, W, lds);
         // Y_j[s, al, be] = Q[al + yl*s, be]
         for (long long e = tid; e < (long long)mm * rnew; e += TTN_WG) {
             const int row = (int)(e % mm), be = (int)(e / mm);
@@ -118,22 +185,30 @@ __global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
         double* Xj = X.data + (long long)b * X.stride + X.off[j];
         double* Yj = Y.data + (long long)b * Y.stride + Y.off[j];
         const int mm = ynext * n;
+        double* Rn = whichL ? Rc : Rd;
+        // the whole step in registers and LDS when the site is a tall QTT core of rank <= 64 (ttn_ortho_fused.h); 0 = not taken / refused
+        int rnew = 0;
+        if (n == 2 && rl <= 64 && rr <= 64 && ynext <= 64 && mm > rl && !(P.no_cholqr & 2))
+            rnew = ortho_step_fused(Xj, Yj, whichL ? Rd : Rc, Rn, rl, rr, ynext, lds, Cw.stamps ? Cw.stamps + 8 : nullptr);
+        if (!rnew) {
         // Tt[(be + ynext*s), al] = sum_ga FL[ga,be] X_j[s,al,ga]  ==  (FL^T) * X2,  X2[ga, (s + n*al)]
         const View X2 = mkview(Xj, plain((long long)n * rl), plain(1));
         const View Tv = mkview(Tm, plain(1), Idx{n, (long long)ynext, (long long)mm});
         wg_gemm(ynext, n * rl, rr, tview(FL), X2, Tv, 1.0, 0.0, lds);
-        double* Rn = whichL ? Rc : Rd;
-        const int rnew = wg_qr_explicit(mm, rl, Tm, Qb, Rn, W, lds);
+        rnew = (rl <= 64 && mm > rl && !(P.no_cholqr & 1)) ? wg_qr_cholqr(mm, rl, Tm, Qb, Rn, Cw, lds) : 0;
+        if (!rnew) rnew = wg_qr_explicit(mm, rl, Tm, Qb, Rn, W, lds);
         // Y_j[s, al, be] = Qt[(be + ynext*s), al]   (core shape (n, rnew, ynext))
-        for (long long e = tid; e < (long long)mm * rnew; e += TTN_WG) {
-            const int row = (int)(e % mm), al = (int)(e / mm);
+        for (int e = tid; e < mm * rnew; e += TTN_WG) {
+            const int row = e % mm, al = e / mm;
             const int be = row % ynext, s = row / ynext;
             Yj[s + (long long)n * (al + (long long)rnew * be)] = Qb[e];
+        }
         }
         if (tid == 0) yr[j] = rnew;
         __syncthreads();
         FL = tview(mkview(Rn, plain(1), plain(rnew)));    // FL[ga, be] = Rt[be, ga]  (rl x rnew)
         whichL ^= 1;
+        if (P.prof && tid == 0 && d - 1 - j < 120) P.prof[16LL * gridDim.x + 120LL * b + (d - 1 - j)] = (long long)__builtin_amdgcn_s_memtime();
     }
     // ---- centre core: Y_i[s] = FR * X_i[s] * FL  (src/tt_tools.jl:537-541) ----
     {

@@ -509,7 +509,7 @@ def test_headline_config_singular_values(T, seed):
 
 # The seeds bench.py times are 30 .. 1053.  The 96-row step at the right end of the L->R half (bond step 24) takes the Gram route
 # finished by the Jacobi polish up to a kept-block conditioning of FAST_KAPPA_POLISH = 32768; over those 1024 seeds the
-# conditioning of that step reaches 4.45e4 (tests/diag_kappa_batch.py 1024 24, round 2).  The 16 worst seeds — two beyond the
+# conditioning of that step reaches 4.45e4 (tools/diag_kappa_batch.py 1024 24, round 2).  The 16 worst seeds — two beyond the
 # limit (Householder route), the others between 6.8e3 and 3.0e4 (polish route AT its acceptance limit) — lead the list; the
 # rest are a spread of ordinary seeds of the same batch.
 BENCH_WORST_KAPPA_SEEDS = [490, 1004, 82, 243, 371, 274, 646, 294, 153, 857, 963, 726, 212, 90, 962, 422]
@@ -526,7 +526,7 @@ def test_bench_batch_parity(T):
     one-sided Jacobi on the device) agree on its small values to c * K * eps * sigma_1 in ABSOLUTE terms only (measured: up to
     1.2e-12 sigma_1), and they leave DIFFERENT (equally valid) cores in the directions of those values; the next steps' merged
     matrices — formed from these non-orthogonal U sqrt(S) cores — inherit that: measured over these trains with three builds
-    (tests/diag_sv_batch.py), the smallest kept value of step 35 (4e-2 sigma_1, conditioning 25) deviates by 1.7e-12 ... 6.6e-12 sigma_1
+    (tools/diag_sv_batch.py), the smallest kept value of step 35 (4e-2 sigma_1, conditioning 25) deviates by 1.7e-12 ... 6.6e-12 sigma_1
     and the deviation decays over the following steps (3e-12, 1e-12, 5e-13), while the tensors agree to 1e-13.  Before step 34
     nothing exceeds 1e-13 sigma_1."""
     d, r = 30, 64
@@ -687,7 +687,7 @@ def test_compress_ranks_up_to_128_blocked_jacobi(T, d, r, mb):
     """Merged short side 128 < p <= 256 (ranks 65..128): Householder LQ + the blocked LDS Jacobi (column blocks of 32 of a
     matrix that lives in global memory).  Ranks exact, tensor 1e-9 against the oracle; per-bond singular values rtol 1e-10
     with atol 1e-12*sigma_1: at these sizes (256 x 512 merged matrices, 30 un-gauged steps each feeding the next) device and
-    LAPACK trajectories drift apart by a few 1e-13*sigma_1 (measured 2e-13..7e-13, tests/diag_sv_err.py), the same size for the
+    LAPACK trajectories drift apart by a few 1e-13*sigma_1 (measured 2e-13..7e-13, tools/diag_sv_err.py), the same size for the
     blocked and the in-LDS Householder — the 1e-13 of the rank-64 tests is too tight here."""
     x = T.rand_tt((2,) * d, r, seed=4)
     A = T.Delta(d)
@@ -945,7 +945,7 @@ def test_krylov_linsolve_steppers_match_dense_solves(T, case):
 
 def test_randomized_apply_compress_parity(T):
     """60 random problems (d 2..10, dims 2..4, x ranks 1..19, operator ranks 1..3, max_bond 1..23, truncerr in {0, 1e-10, 1e-6,
-    1e-3}) through the fused ttn_apply_compress: ranks exact, tensor 1e-9 against the oracle.  (tests/diag_fuzz.py runs the
+    1e-3}) through the fused ttn_apply_compress: ranks exact, tensor 1e-9 against the oracle.  (tools/diag_fuzz.py runs the
     same generator for any count; 400 cases were clean on the round-1 build.)"""
     rng = np.random.default_rng(1)
     for it in range(60):

@@ -1,5 +1,5 @@
 """Diagnostic (not a test): als_linsolve on the 2D Laplace problem of examples/Laplace_pde.jl (serial QTT ordering,
-d bits per dimension), device vs the CPU oracle.   python tests/diag_als.py [bits] [rank] [batch] [sweeps]"""
+d bits per dimension), device vs the CPU oracle.   python tools/diag_als.py [bits] [rank] [batch] [sweeps]"""
 import math
 import sys
 import time

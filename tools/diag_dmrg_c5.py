@@ -1,5 +1,5 @@
 """Diagnostic (not a test): two-site DMRG with the matrix-free CG local solver on the 2D Laplace problem of examples/Laplace_pde.jl at
-BASELINE config C5 size (2 x 12 bits, rank up to 128 -> local systems of 65 536 unknowns).   python tests/diag_dmrg_c5.py [rank] [batch] [maxiter]"""
+BASELINE config C5 size (2 x 12 bits, rank up to 128 -> local systems of 65 536 unknowns).   python tools/diag_dmrg_c5.py [rank] [batch] [maxiter]"""
 import math
 import sys
 import time

@@ -1,5 +1,5 @@
 """Diagnostic (not a test): fine-grained cycle counters of ONE bond step (TTN_PROF_STEP=k) of the fused apply+round, median over the
-trains of the batch.  Usage: TTN_PROF_STEP=40 [TTN_WG512=1] python tests/diag_fine.py [batch]"""
+trains of the batch.  Usage: TTN_PROF_STEP=40 [TTN_WG512=1] python tools/diag_fine.py [batch]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("TTN_PROF", "1")

@@ -1,5 +1,5 @@
 """Diagnostic: targeted parity fuzz of the steps that take the eigensolver routes (n = 2, rank-64 trains: 128-row Gram steps,
-64 x 64 route-F cores) against the oracle: operators, seeds, max_bond, truncerr.   python tests/diag_fuzz_eig.py [N] [seed]"""
+64 x 64 route-F cores) against the oracle: operators, seeds, max_bond, truncerr.   python tools/diag_fuzz_eig.py [N] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

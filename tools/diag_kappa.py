@@ -1,5 +1,5 @@
 """Diagnostic: conditioning of the kept block of every bond step of the C3 sweep (sigma_1 / sigma_r) and the numerical rank.
-   python tests/diag_kappa.py [d] [rank]"""
+   python tools/diag_kappa.py [d] [rank]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,5 @@
 """Diagnostic: distribution over a batch of the conditioning s1/s_kept of one bond step of the C3 sweep.
-   python tests/diag_kappa_batch.py [B] [step]"""
+   python tools/diag_kappa_batch.py [B] [step]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,5 @@
 """Diagnostic: phase counters of single bond steps of the C3 sweep (unfused: y = A x is materialised first).
-   TTN_PROF=1 python tests/diag_step.py k [k2 ...]   (1-based bonds of the L->R half sweep)"""
+   TTN_PROF=1 python tools/diag_step.py k [k2 ...]   (1-based bonds of the L->R half sweep)"""
 import ctypes as C
 import os
 import sys

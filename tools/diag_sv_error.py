@@ -1,5 +1,5 @@
 """Diagnostic: per-bond-step relative error of the kept singular values of the fused apply+round against the CPU oracle.
-   python tests/diag_sv_error.py [d] [rank] [seed]"""
+   python tools/diag_sv_error.py [d] [rank] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,5 @@
 """Diagnostic (not a test): timing of the site-swap chains on the device vs the CPU oracle.
-   python tests/diag_swap.py [d] [rx] [ry] [batch]"""
+   python tools/diag_swap.py [d] [rx] [ry] [batch]"""
 import sys
 import time
 
