@@ -126,15 +126,14 @@ def test_c5_dmrg_matrix_free_reference_defaults(T, problem, rank):
     """dmrg_linsolve with the REFERENCE's default local solver (it_solver = true, linsolv_maxiter = 200, linsolv_tol =
     max(sqrt(tol), 1e-8); dmrg.jl:392-395) from a random rank-`rank` start train: two-site systems of 4 * rank^2 = 4096 / 16384 /
     65536 unknowns (rank 128 = BASELINE config C5's stated rank bound) — beyond the dense path — solved matrix-free by conjugate
-    gradients on the device (wg_cg_two_site).  KrylovKit's selector runs CG(maxiter = krylovdim * linsolv_maxiter = 6000)
-    (euler.jl:29 spells the convention out), so with cond(A) = 1.7e7 the local solves now CONVERGE to linsolv_tol (1e-5 absolute)
-    in a few hundred to a few thousand iterations instead of stopping at 200.
+    gradients on the device (wg_cg_two_site).  KrylovKit's algorithm selector runs CG(maxiter = krylovdim * linsolv_maxiter =
+    6000) for this call (the convention src/solvers/euler.jl:29 spells out; round 2 capped the iteration at 200 on both sides and
+    every local solve ended unconverged): with the real cap the local solves CONVERGE to linsolv_tol, and device and oracle
+    agree — same ranks, same residual to four digits, iterate 3e-11 at rank 32 (measured, round 3).
     Oracle: run live at rank 32 (5 s); at ranks 64 / 128 its result comes from tests/golden/c5_matrix_free_rank<R>.json
-    (tests/golden/make_c5_golden.py: 1 min / ~1 h of CPU), same seed.  Asserted: gauge flags exact, total CG iterations within
-    10 %, residual after the sweep within a factor 2 of the oracle's, final ranks equal wherever ... (printed; the ranks are cut
-    by cut_off_index at tol * ||s||, inside the rounding noise of a cond-1.7e7 solve, so they are compared loosely: max rank within
-    +-2).  The iterate itself is compared at rank 32 (tensor difference printed and bounded by 1e-4: both sides solve every local
-    system to 1e-5 ABSOLUTE only)."""
+    (tests/golden/make_c5_golden.py: 1 min / 40 min of CPU), same seed.  Asserted: final ranks (exact at ranks 32 / 64, within one per bond at rank 128) and gauge flags exact, total CG
+    iterations within 10 % (the iteration count of a cond-1.7e7 solve is sensitive to the summation order), residual after the
+    sweep equal to 1e-3 relative; at rank 32 also the iterate as a tensor (1e-8)."""
     A, b = problem
     rng = np.random.default_rng(9)
     x0 = O.rand_tt((2,) * A.N, rank, rng)
@@ -153,13 +152,19 @@ def test_c5_dmrg_matrix_free_reference_defaults(T, problem, rank):
     print(f"C5 matrix-free rank {rank}: CG iterations device {iters} / oracle {gold['cg_iterations']}, residual device {rg:.3e} / oracle {rr:.3e}, "
           f"ranks device {list(got.ttv_rks)} / oracle {gold['ranks']}")
     assert abs(iters - gold["cg_iterations"]) <= 0.1 * gold["cg_iterations"]
-    assert np.isfinite(rg) and 0.5 * rr <= rg <= 2.0 * rr, (rg, rr)
+    assert np.isfinite(rg) and abs(rg - rr) <= 1e-3 * rr, (rg, rr)
     assert list(got.ttv_ot) == gold["ot"]
-    assert abs(max(got.ttv_rks) - max(gold["ranks"])) <= 2
+    if rank <= 64:
+        assert list(got.ttv_rks) == gold["ranks"], (list(got.ttv_rks), gold["ranks"])
+    else:
+        # rank 128: cut_off_index cuts at tol * ||s|| = 1e-10 ||s||, inside the rounding noise of the cond-1.7e7 local solves of the
+        # 65 536-unknown windows — measured: two bonds keep one singular value more than the oracle (6 against 5), everything
+        # else equal, residual equal to four digits.  A rank decision inside the noise is parity-unpinned: bound it by one per bond.
+        assert all(abs(a - c) <= 1 for a, c in zip(got.ttv_rks, gold["ranks"])), (list(got.ttv_rks), gold["ranks"])
     if ref is not None:
         err = tt_rel_diff(to_oracle(got), ref)
         print(f"C5 matrix-free rank 32: iterate rel. difference device vs oracle {err:.2e}")
-        assert err <= 1e-4
+        assert err <= 1e-8
 
 
 def test_dmrg_default_rmax_schedule_is_clamped_not_refused(T, problem):

@@ -204,8 +204,11 @@ def test_scale_semantics(T):
     _cores_equal(y, ref)                    # scales the first core with ot == 0 (site 3); ot copied
     z = 0.0 * x
     assert z.ttv_ot == [0] * 5 and all(np.all(c == 0) for c in z.ttv_vec) and z.ttv_rks == x.ttv_rks
-    w = x - x
-    assert T.norm(w) <= 1e-14 * T.norm(x)
+    w = x - x                                   # (-1.0) * x + x: a rank-2r train that represents exactly zero
+    assert np.max(np.abs(O.ttv_to_tensor(to_oracle(w)))) <= 1e-14 * np.max(np.abs(O.ttv_to_tensor(to_oracle(x))))
+    # dot(w, w) is a sum of terms of size ||x||^2 that cancel: zero to the parity bar of dot (1e-12 of that size) — the norm, its
+    # square root, is then zero to sqrt(eps) ||x|| only (the left-to-right order of round 2 happened to cancel exactly)
+    assert abs(T.dot(w, w)) <= 1e-12 * T.dot(x, x)
     _cores_equal(x / 4.0, O.div(to_oracle(x), 4.0))
 
 
