@@ -500,7 +500,7 @@ def bench_op(args, T, D):
     for b in range(B):
         dx.upload(b, T.rand_tt(dims, r, seed=30 + b))
     core_bytes = lambda rk: 8.0 * sum(2 * rk[k] * rk[k + 1] for k in range(d))          # noqa: E731
-    bound, flops, nbytes, kernel = "hbm", 0.0, 0.0, "k_" + op
+    bound, flops, nbytes, kernel = "hbm", 0.0, 0.0, ("k_dot_fused" if op == "dot" else "k_" + op)
     if op == "apply":
         yr = [a * c for a, c in zip(A.tto_rks, xr)]
         dy = T.DeviceTT(dims, yr, batch=B)
