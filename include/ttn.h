@@ -154,7 +154,10 @@ int ttn_ttv_decomp(ttn_tt_t z, const double* tensors, int64_t index, double tol)
  * sweep_count half sweeps, for every train of the batch (one operator, `batch` right-hand sides b and start trains x0).
  * x receives orthogonalize(x0) first (als.jl:174) and keeps x0's ranks (als.jl:177); the local systems are assembled
  * densely and solved by LU with partial pivoting like the reference's `K \ Pb` (als.jl:58-70).  All trains of x0 must carry
- * the same ranks; n r_{i-1} r_i <= 2048.  ttn_compress_status(x) reports a singular local system (TTN_ERR_SINGULAR). */
+ * the same ranks.  Local systems of up to 2048 unknowns (n r_{i-1} r_i: ranks up to 32 for n = 2) run as ONE persistent launch, one
+ * workgroup per train; larger ones — up to 65 536 unknowns; BASELINE config C5 names ranks up to 128 = 32 768 unknowns, an 8.6 GB K —
+ * run in the GRID form: assembly and the blocked LU on the whole chip, the half sweeps walked by the host, one train after the other
+ * (csrc/ttn_als_grid.h).  ttn_compress_status(x) reports a singular local system (TTN_ERR_SINGULAR). */
 int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t sweep_count);
 
 /* mals_linsolve(A, b, tt_start; tol, rmax) (src/solvers/mals.jl:240-312): one forward and one backward half sweep of

@@ -22,6 +22,11 @@ struct AlsArgs {
     int mmax, rmax;
     int* status;                 // [batch]: 0 ok, 3 singular local system, 4 ranks differ from the handle's bound
     const long long* rfix;       // device [d+1]: the fixed ranks of x
+    // The GRID form for local systems too large for one workgroup (ttn_api.hip: als_grid_path): the host walks the half sweeps and runs
+    // the same kernel phase by phase for ONE train (train0; its scratch at `scratch`), the assembly of K and the LU on the whole chip
+    // in between.  phase 0: the whole solve in one launch (the one-workgroup form); 1: rank check + initial environments; 2 / 3: the
+    // core move and environment update after the local solve of `site` in a forward / backward half sweep (V in the Pb slot).
+    int phase, site, train0;
 };
 
 // Dense solve K v = rhs (in place, v overwrites rhs); K is N x N column-major (destroyed).  Blocked right-looking LU with
@@ -321,9 +326,9 @@ __device__ __noinline__ void als_update_G(const AlsEnv& E, int i) {
 
 __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
     extern __shared__ double lds[];
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int tid = threadIdx.x, b = blockIdx.x + P.train0;
     const int d = P.x.d;
-    double* scr = P.scratch + (long long)b * P.scratch_stride;
+    double* scr = P.scratch + (long long)blockIdx.x * P.scratch_stride;
     double* red = lds + GEMM_LDS_TOTAL;
     int* iflag = reinterpret_cast<int*>(red + 32 + 2 * QR_NB * QR_NB + QR_NB + 8);
     OrthoWork W;
@@ -337,7 +342,7 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
     double* Qb = scr + P.offQb;
     double* Rb = scr + P.offRb;
     // the ranks are fixed (als.jl:177): every train must carry exactly the handle's ranks
-    {
+    if (P.phase <= 1) {
         const long long* xr = P.x.rks + (long long)b * (d + 1);
         bool bad = false;
         for (int k = 0; k <= d; ++k) bad |= (xr[k] != P.rfix[k]);
@@ -419,6 +424,65 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
         return wg_lu_solve(N, K, Pb, reinterpret_cast<int*>(scr + P.offPiv), red, iflag, lds) == 0;
     };
 
+    // the core move and environment update that follow the local solve of site i (V in Pb): forward half sweep (als.jl:122-135) ...
+    auto fwd_move = [&](int i) {
+        const AlsSite s = SITE(i);
+        const int mm = s.n * s.rl;
+        WG_FOR((long long)mm * s.rr) Tm[e_] = Pb[e_];
+        __syncthreads();
+        wg_qr_explicit(mm, s.rr, Tm, Qb, Rb, W, lds);                           // right_core_move (als.jl:122-135)
+        double* xi = XC(i);
+        WG_FOR((long long)mm * s.rr) xi[e_] = Qb[e_];
+        // x_{i+1}[a, b, c] = sum_z R[b, z] x_{i+1}[a, z, c]
+        const AlsSite s2 = SITE(i + 1);
+        double* xn = XC(i + 1);
+        WG_FOR((long long)s2.n * s2.rl * s2.rr) {
+            long long t = e_; const int a_ = t % s2.n; t /= s2.n; const int bq = t % s2.rl; const int c = (int)(t / s2.rl);
+            double a = 0.0;
+            for (int z = 0; z < s2.rl; ++z) a = fma(Rb[bq + (long long)s.rr * z], xn[a_ + s2.n * (z + (long long)s2.rl * c)], a);
+            T1[e_] = a;
+        }
+        __syncthreads();
+        WG_FOR((long long)s2.n * s2.rl * s2.rr) xn[e_] = T1[e_];
+        __syncthreads();
+        als_update_G(E, i);
+    };
+    // ... and backward half sweep (als.jl:102-120)
+    auto bwd_move = [&](int i) {
+        const AlsSite s = SITE(i);
+        const int mm = s.n * s.rr;
+        // M[(x + n*a2), a1] = V[x, a1, a2]                                      left_core_move (als.jl:102-120)
+        WG_FOR((long long)mm * s.rl) {
+            const int row = (int)(e_ % mm), a1 = (int)(e_ / mm);
+            const int xx = row % s.n, a2 = row / s.n;
+            Tm[e_] = Pb[xx + s.n * (a1 + (long long)s.rl * a2)];
+        }
+        __syncthreads();
+        wg_qr_explicit(mm, s.rl, Tm, Qb, Rb, W, lds);
+        double* xi = XC(i);
+        WG_FOR((long long)mm * s.rl) {
+            const int row = (int)(e_ % mm), a1 = (int)(e_ / mm);
+            const int xx = row % s.n, a2 = row / s.n;
+            xi[xx + s.n * (a1 + (long long)s.rl * a2)] = Qb[e_];
+        }
+        // x_{i-1}[a, b, c] = sum_z x_{i-1}[a, b, z] R[c, z]
+        const AlsSite s0 = SITE(i - 1);
+        double* xp = XC(i - 1);
+        WG_FOR((long long)s0.n * s0.rl * s0.rr) {
+            const long long ab = e_ % ((long long)s0.n * s0.rl);
+            const int c = (int)(e_ / ((long long)s0.n * s0.rl));
+            double a = 0.0;
+            for (int z = 0; z < s0.rr; ++z) a = fma(xp[ab + (long long)s0.n * s0.rl * z], Rb[c + (long long)s.rl * z], a);
+            T1[e_] = a;
+        }
+        __syncthreads();
+        WG_FOR((long long)s0.n * s0.rl * s0.rr) xp[e_] = T1[e_];
+        __syncthreads();
+        update_H(i);
+    };
+
+    if (P.phase == 2) { fwd_move(P.site); return; }
+    if (P.phase == 3) { bwd_move(P.site); return; }
     // ---- initial environments (als.jl:183-193): G_1, Gb_1 from the first cores, H / Hb from the right ----
     {
         const AlsSite s = SITE(0);
@@ -428,6 +492,7 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
         __syncthreads();
     }
     for (int i = d - 1; i >= 1; --i) update_H(i);
+    if (P.phase == 1) return;
     bool ok = true;
     int nsweeps = 0;
     while (nsweeps < P.sweep_count && ok) {
@@ -435,62 +500,14 @@ __global__ void __launch_bounds__(TTN_WG) k_als_linsolve(AlsArgs P) {
         for (int i = 0; i < d - 1 && ok; ++i) {                                     // first half sweep (als.jl:199-207)
             ok = ksolve(i);
             if (!ok) break;
-            const AlsSite s = SITE(i);
-            const int mm = s.n * s.rl;
-            WG_FOR((long long)mm * s.rr) Tm[e_] = Pb[e_];
-            __syncthreads();
-            wg_qr_explicit(mm, s.rr, Tm, Qb, Rb, W, lds);                           // right_core_move (als.jl:122-135)
-            double* xi = XC(i);
-            WG_FOR((long long)mm * s.rr) xi[e_] = Qb[e_];
-            // x_{i+1}[a, b, c] = sum_z R[b, z] x_{i+1}[a, z, c]
-            const AlsSite s2 = SITE(i + 1);
-            double* xn = XC(i + 1);
-            WG_FOR((long long)s2.n * s2.rl * s2.rr) {
-                long long t = e_; const int a_ = t % s2.n; t /= s2.n; const int bq = t % s2.rl; const int c = (int)(t / s2.rl);
-                double a = 0.0;
-                for (int z = 0; z < s2.rl; ++z) a = fma(Rb[bq + (long long)s.rr * z], xn[a_ + s2.n * (z + (long long)s2.rl * c)], a);
-                T1[e_] = a;
-            }
-            __syncthreads();
-            WG_FOR((long long)s2.n * s2.rl * s2.rr) xn[e_] = T1[e_];
-            __syncthreads();
-            als_update_G(E, i);
+            fwd_move(i);
         }
         if (nsweeps == P.sweep_count || !ok) break;
         ++nsweeps;
         for (int i = d - 1; i >= 1 && ok; --i) {                                    // second half sweep (als.jl:213-219)
             ok = ksolve(i);
             if (!ok) break;
-            const AlsSite s = SITE(i);
-            const int mm = s.n * s.rr;
-            // M[(x + n*a2), a1] = V[x, a1, a2]                                      left_core_move (als.jl:102-120)
-            WG_FOR((long long)mm * s.rl) {
-                const int row = (int)(e_ % mm), a1 = (int)(e_ / mm);
-                const int xx = row % s.n, a2 = row / s.n;
-                Tm[e_] = Pb[xx + s.n * (a1 + (long long)s.rl * a2)];
-            }
-            __syncthreads();
-            wg_qr_explicit(mm, s.rl, Tm, Qb, Rb, W, lds);
-            double* xi = XC(i);
-            WG_FOR((long long)mm * s.rl) {
-                const int row = (int)(e_ % mm), a1 = (int)(e_ / mm);
-                const int xx = row % s.n, a2 = row / s.n;
-                xi[xx + s.n * (a1 + (long long)s.rl * a2)] = Qb[e_];
-            }
-            // x_{i-1}[a, b, c] = sum_z x_{i-1}[a, b, z] R[c, z]
-            const AlsSite s0 = SITE(i - 1);
-            double* xp = XC(i - 1);
-            WG_FOR((long long)s0.n * s0.rl * s0.rr) {
-                const long long ab = e_ % ((long long)s0.n * s0.rl);
-                const int c = (int)(e_ / ((long long)s0.n * s0.rl));
-                double a = 0.0;
-                for (int z = 0; z < s0.rr; ++z) a = fma(xp[ab + (long long)s0.n * s0.rl * z], Rb[c + (long long)s.rl * z], a);
-                T1[e_] = a;
-            }
-            __syncthreads();
-            WG_FOR((long long)s0.n * s0.rl * s0.rr) xp[e_] = T1[e_];
-            __syncthreads();
-            update_H(i);
+            bwd_move(i);
         }
     }
     if (!ok && tid == 0) ttn_set_status(&P.status[b], 3);

@@ -7,6 +7,7 @@
 #include "ttn_ortho_kernels.h"
 #include "ttn_hsvd_kernels.h"
 #include "ttn_als_kernels.h"
+#include "ttn_als_grid.h"
 #include "ttn_eig_kernels.h"
 #include "ttn_tdvp_kernels.h"
 
@@ -1135,6 +1136,83 @@ int ttn_ttv_decomp(ttn_tt_t z, const double* tensors, int64_t index, double tol)
 }
 
 // ---- als_linsolve ------------------------------------------------------------------------------------------------
+#define TTN_DENSE_LOCAL_MAX_ALS 2048
+// The grid form of als_linsolve (csrc/ttn_als_grid.h): for every train in turn the half sweeps of src/solvers/als.jl:199-219 walked on
+// the host — per site the assembly of K (grid), the blocked LU with partial pivoting panel by panel (panel: one workgroup; row
+// interchanges + U12: grid; trailing MFMA update: grid), the back substitution, then the core move and environment update (phase 2 / 3
+// of k_als_linsolve, one workgroup).  Everything is enqueued on the library stream; one flag word carries a singular pivot column.
+static int als_grid_path(AlsArgs P, const std::vector<long long>& off, const std::vector<int64_t>& r, ttn_tto_t A, ttn_tt_t b, ttn_tt_t x, int sweep_count) {
+    const int d = x->d, batch = x->batch;
+    static bool attr = false;
+    const size_t panel_lds = sizeof(double) * (128 * 128 + 64 + 64);
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lu_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lu_trail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * GEMM_LDS_TOTAL)));
+        attr = true;
+    }
+    double* scr = P.scratch;
+    double* K = scr + P.offK;
+    double* Pb = scr + P.offPb;
+    int* piv = reinterpret_cast<int*>(scr + P.offPiv);
+    static int* d_flag = nullptr;
+    if (!d_flag) HIPCHK(hipMalloc((void**)&d_flag, sizeof(int)));
+    const std::vector<int64_t>& R = A->rks;
+    auto solve_site = [&](int i) -> int {
+        const int n = (int)x->dims[i], rl = (int)r[i], rr = (int)r[i + 1];
+        const int nr = n * rl, N = nr * rr;
+        AlsAssembleArgs Q;
+        Q.G = scr + off[i]; Q.Gb = scr + off[d + i]; Q.H = scr + off[2 * d + i]; Q.Hb = scr + off[3 * d + i];
+        Q.K = K; Q.Pb = Pb; Q.nr = nr; Q.rr = rr; Q.Rr = (int)R[i + 1]; Q.br = (int)b->bound[i + 1];
+        hipLaunchKernelGGL(k_als_assemble, dim3((N + ALS_ASM_ROWS - 1) / ALS_ASM_ROWS, (N + ALS_ASM_COLS - 1) / ALS_ASM_COLS), dim3(ALS_ASM_ROWS), 0, g_stream, Q);
+        for (int k0 = 0; k0 < N; k0 += LU_NB) {
+            const int w = std::min(LU_NB, N - k0);
+            hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(TTN_WG), panel_lds, g_stream, K, N, k0, w, piv, d_flag);
+            hipLaunchKernelGGL(k_lu_rows, dim3((N + 1 + 255) / 256), dim3(256), 0, g_stream, K, Pb, N, k0, w, (const int*)piv, (const int*)d_flag);
+            const int m = N - k0 - w;
+            if (m > 0) {
+                const int nt = (m + LU_TILE - 1) / LU_TILE;
+                hipLaunchKernelGGL(k_lu_trail, dim3(nt, nt), dim3(TTN_WG), sizeof(double) * GEMM_LDS_TOTAL, g_stream, K, Pb, N, k0, w, (const int*)d_flag);
+            }
+        }
+        for (int kb = ((N - 1) / 32) * 32; kb >= 0; kb -= 32) {
+            const int wb = std::min(32, N - kb);
+            hipLaunchKernelGGL(k_lu_back_tri, dim3(1), dim3(64), 0, g_stream, (const double*)K, Pb, N, kb, wb, (const int*)d_flag);
+            if (kb > 0) hipLaunchKernelGGL(k_lu_back_rows, dim3((kb + 255) / 256), dim3(256), 0, g_stream, (const double*)K, Pb, N, kb, wb, (const int*)d_flag);
+        }
+        HIPCHK(hipGetLastError());
+        return TTN_OK;
+    };
+    auto phase = [&](int ph, int site, int tb) -> int {
+        AlsArgs Q = P;
+        Q.phase = ph; Q.site = site; Q.train0 = tb;
+        hipLaunchKernelGGL(k_als_linsolve, dim3(1), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, Q);
+        HIPCHK(hipGetLastError());
+        return TTN_OK;
+    };
+    for (int tb = 0; tb < batch; ++tb) {
+        HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(int), g_stream));
+        int rc = phase(1, 0, tb);
+        if (rc) return rc;
+        int nsweeps = 0;
+        while (nsweeps < sweep_count) {
+            ++nsweeps;
+            for (int i = 0; i < d - 1; ++i) { if ((rc = solve_site(i))) return rc; if ((rc = phase(2, i, tb))) return rc; }
+            if (nsweeps == sweep_count) break;
+            ++nsweeps;
+            for (int i = d - 1; i >= 1; --i) { if ((rc = solve_site(i))) return rc; if ((rc = phase(3, i, tb))) return rc; }
+        }
+        int h_flag = 0;
+        HIPCHK(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        if (h_flag) {                                   // LAPACK's SingularException: recorded on the handle like the one-workgroup form does
+            const int three = 3;
+            HIPCHK(hipMemcpyAsync(x->d_status + tb, &three, sizeof(int), hipMemcpyHostToDevice, g_stream));
+            HIPCHK(hipStreamSynchronize(g_stream));
+        }
+    }
+    return TTN_OK;
+}
+
 int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t sweep_count) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     NEED_INIT();
@@ -1170,7 +1248,10 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
         t1 = std::max(t1, std::max(std::max(Rr * rr * n * rl, n * rl * rr * std::max(Rl, Rr)), std::max(rr * n * bl, std::max(rr * br, rl * br))));
         t2 = std::max(t2, std::max(n * rr * Rl * rl, rr * rr * Rr));
     }
-    if (Nmax > 2048) return fail(TTN_ERR_UNSUPPORTED, "ttn_als_linsolve: local systems above 2048 unknowns are not supported by the one-workgroup LU");
+    // Local systems above 2048 unknowns (ranks above 32 for n = 2 — BASELINE config C5 names ranks up to 128: 32 768 unknowns, an 8.6 GB
+    // matrix): the GRID form — assembly and LU on the whole chip, the host walks the half sweeps (als_grid_path below).
+    const bool grid_path = Nmax > TTN_DENSE_LOCAL_MAX_ALS || (getenv("TTN_ALS_GRID") && atoi(getenv("TTN_ALS_GRID")) != 0);
+    if (Nmax > 65536) return fail(TTN_ERR_UNSUPPORTED, "ttn_als_linsolve: local systems above 65 536 unknowns are not supported");
     AlsArgs P;
     memset(&P, 0, sizeof(P));
     P.offK = cur; cur += Nmax * Nmax;
@@ -1186,14 +1267,15 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
     P.offTst = cur; cur += ((rmax + QR_NB - 1) / QR_NB) * QR_NB * QR_NB + 64;
     const long long per_train = cur;
     const int batch = x->batch;
+    const int nslots = grid_path ? 1 : batch;          // the grid form works on one train at a time (K alone can be gigabytes)
     static std::vector<long long> h_off;               // outlives the async upload
     HIPCHK(hipStreamSynchronize(g_stream));
-    rc = ensure_scratch(sizeof(double) * (size_t)per_train * batch + sizeof(long long) * (size_t)(5 * d + 1) + 64);
+    rc = ensure_scratch(sizeof(double) * (size_t)per_train * nslots + sizeof(long long) * (size_t)(5 * d + 1) + 64);
     if (rc) return rc;
     rc = ensure_batch_bufs(batch);
     if (rc) return rc;
     double* base = (double*)g_scratch;
-    long long* d_tab = (long long*)(base + (size_t)per_train * batch);
+    long long* d_tab = (long long*)(base + (size_t)per_train * nslots);
     h_off = off;
     for (int k = 0; k <= d; ++k) h_off.push_back(r[k]);
     HIPCHK(hipMemcpyAsync(d_tab, h_off.data(), sizeof(long long) * h_off.size(), hipMemcpyHostToDevice, g_stream));
@@ -1204,8 +1286,13 @@ int ttn_als_linsolve(ttn_tto_t A, ttn_tt_t b, ttn_tt_t x0, ttn_tt_t x, int64_t s
     P.rfix = d_tab + 4 * d;
     P.mmax = (int)mmax; P.rmax = (int)rmax;
     P.status = x->d_status;
-    hipLaunchKernelGGL(k_als_linsolve, dim3(batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, P);
-    HIPCHK(hipGetLastError());
+    if (grid_path) {
+        rc = als_grid_path(P, off, r, A, b, x, (int)sweep_count);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_als_linsolve, dim3(batch), dim3(TTN_WG), COMPRESS_LDS_BYTES, g_stream, P);
+        HIPCHK(hipGetLastError());
+    }
     // orthogonality flags as the core moves leave them (als.jl:128-134, :112-118)
     for (int bb = 0; bb < batch; ++bb) {
         int64_t* ot = &x->ot[(size_t)bb * d];

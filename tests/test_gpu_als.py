@@ -139,3 +139,66 @@ def test_als_errors(T):
         T.solvers.als_linsolve(to_product(O.id_tto(d)), b, fat)
     with pytest.raises(AssertionError):
         T.solvers.als_linsolve(to_product(O.id_tto(d)), b, x0, sweep_count=0)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the GRID form (csrc/ttn_als_grid.h): local systems beyond the 2048 unknowns of the one-workgroup LU — assembly and blocked LU on
+# the whole chip, the half sweeps walked on the host
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,r,shift,sweeps", [(8, 4, 0.5, 3), (10, 6, 1.0, 2), (6, 8, 0.0, 4)])
+def test_als_grid_form_equals_one_workgroup_form(T, monkeypatch, d, r, shift, sweeps):
+    """The same problems through both forms (TTN_ALS_GRID=1 forces the grid form on systems the one-workgroup form can take): same
+    operations in the same order, so the iterates agree to rounding; and both agree with the oracle."""
+    rng = np.random.default_rng(300 + d)
+    A = _spd(d, shift)
+    b, x0 = O.rand_tt((2,) * d, 3, rng), O.rand_tt((2,) * d, r, rng)
+    one = T.solvers.als_linsolve(to_product(A), to_product(b), to_product(x0), sweep_count=sweeps)
+    monkeypatch.setenv("TTN_ALS_GRID", "1")
+    grid = T.solvers.als_linsolve(to_product(A), to_product(b), to_product(x0), sweep_count=sweeps)
+    assert list(grid.ttv_rks) == list(one.ttv_rks) and list(grid.ttv_ot) == list(one.ttv_ot) == _ot_after(d, sweeps)
+    assert tt_rel_diff(to_oracle(grid), to_oracle(one)) <= 1e-12
+    assert tt_rel_diff(to_oracle(grid), O.als_linsolve(A, b, x0, sweep_count=sweeps)) <= 1e-9
+
+
+def test_als_grid_form_batch_and_singular_system(T, monkeypatch):
+    """A batch through the grid form (one train after the other) and LAPACK's SingularException: an exactly singular local system
+    (the zero operator) is reported as TTN_ERR_SINGULAR through the handle's status, like the one-workgroup form."""
+    monkeypatch.setenv("TTN_ALS_GRID", "1")
+    rng = np.random.default_rng(77)
+    d = 6
+    A = _spd(d, 2.0)
+    dA = T.DeviceTTO(to_product(A))
+    bs = [O.rand_tt((2,) * d, 2, rng) for _ in range(3)]
+    xs = [O.rand_tt((2,) * d, 4, rng) for _ in range(3)]
+    db, dx0 = T.DeviceTT((2,) * d, bs[0].ttv_rks, batch=3), T.DeviceTT((2,) * d, xs[0].ttv_rks, batch=3)
+    for k in range(3):
+        db.upload(k, to_product(bs[k])); dx0.upload(k, to_product(xs[k]))
+    dx = T.DeviceTT((2,) * d, xs[0].ttv_rks, batch=3)
+    T.solvers.als_linsolve_(dA, db, dx0, dx, 2)
+    T.device.compress_status(dx)
+    for k in range(3):
+        assert tt_rel_diff(to_oracle(dx.download(k)), O.als_linsolve(A, bs[k], xs[k], sweep_count=2)) <= 1e-9
+    Z = O.tto_scale(0.0, O.id_tto(d))
+    with pytest.raises(T._lib.TTNError):
+        T.solvers.als_linsolve(to_product(Z), to_product(bs[0]), to_product(xs[0]))
+
+
+def test_als_rank40_beyond_the_one_workgroup_limit(T):
+    """Rank-40 start train on 2 x 7 bits: one-site systems of 2 * 40 * 40 = 3200 unknowns (> 2048: only the grid form can take them;
+    round 2 refused the call).  Operator: the 2D Laplacian of examples/Laplace_pde.jl scaled by h^2 plus the identity (cond ~ 9), so
+    the iterate is pinned: ranks and gauge flags exact, tensor 1e-9, residual equal."""
+    rng = np.random.default_rng(11)
+    dd = 7
+    L1, I1 = O.toeplitz_to_qtto(2.0, -1.0, -1.0, dd), O.id_tto(dd)
+    kron = lambda P_, Q_: O.TToperator(P_.N + Q_.N, list(P_.tto_vec) + list(Q_.tto_vec), tuple(P_.tto_dims) + tuple(Q_.tto_dims),   # noqa: E731
+                                       list(P_.tto_rks[:-1]) + list(Q_.tto_rks), [0] * (P_.N + Q_.N))
+    A = O.tto_add(O.tto_add(kron(L1, I1), kron(I1, L1)), kron(I1, I1))
+    d = 2 * dd
+    b = O.rand_tt((2,) * d, 3, rng)
+    x0 = O.rand_tt((2,) * d, 40, rng)
+    assert max(2 * x0.ttv_rks[i] * x0.ttv_rks[i + 1] for i in range(d)) == 3200
+    ref = O.als_linsolve(A, b, x0, sweep_count=2)
+    got = T.solvers.als_linsolve(to_product(A), to_product(b), to_product(x0), sweep_count=2)
+    assert list(got.ttv_rks) == list(ref.ttv_rks) and list(got.ttv_ot) == list(ref.ttv_ot)
+    assert tt_rel_diff(to_oracle(got), ref) <= 1e-9
+    assert abs(_resid(A, to_oracle(got), b) - _resid(A, ref, b)) <= 1e-9

@@ -83,6 +83,25 @@ def test_c5_als_rank32_largest_dense_system(T, problem):
     assert np.isfinite(rg) and rg <= 10.0 * rr + 1e-6, (rg, rr)
 
 
+def test_c5_als_rank64_grid_form(T, problem):
+    """Rank 64 on the C5 problem: one-site systems of 2 * 64 * 64 = 8192 unknowns (a 0.5 GB K per site), four times the limit of the
+    one-workgroup LU — the grid form (csrc/ttn_als_grid.h: assembly and blocked LU with partial pivoting on the whole chip).  The
+    oracle needs ~10 min of CPU for this run, so only oracle-independent facts are asserted: the ranks stay those of the start train
+    (als.jl:177), the gauge flags are the sweep's, and the residual after two half sweeps is at the level the rank-32 run reaches
+    against its oracle (3e-3; the start train's residual is O(1)).  The iterate itself is pinned at a size the oracle can take:
+    tests/test_gpu_als.py::test_als_rank40_beyond_the_one_workgroup_limit (3200 unknowns, tensor 1e-9)."""
+    A, b = problem
+    rng = np.random.default_rng(6)
+    x0 = O.rand_tt((2,) * A.N, 64, rng)
+    assert max(2 * x0.ttv_rks[i] * x0.ttv_rks[i + 1] for i in range(A.N)) == 8192
+    got = T.solvers.als_linsolve(to_product(A), to_product(b), to_product(x0), sweep_count=2)
+    assert list(got.ttv_rks) == list(x0.ttv_rks)
+    assert list(got.ttv_ot) == [0] + [1] * (A.N - 1)                                    # forward, then backward half sweep: the centre is site 1 (als.jl:112-118)
+    rg = _resid(A, to_oracle(got), b)
+    print(f"C5 als rank 64 (grid form): residual {rg:.3e}")
+    assert np.isfinite(rg) and rg <= 2e-2
+
+
 def test_c5_mals(T, problem):
     """mals_linsolve(A, b, x0) as examples/Laplace_pde.jl:26 calls it (one sweep, tol 1e-12), rmax 22: two-site systems up to
     4 * 22 * 22 = 1936 unknowns."""
