@@ -197,6 +197,7 @@ end
 #
 # Status is sticky per handle: ttn_compress_status(h, C_NULL) returns the first error any compress / sweep / swap / solver call
 # recorded on h since the last query (capacity -5, Jacobi sweep limit -9, singular local system -10) and clears it.
+# ccall((:ttn_status_all, LIB), Cint, ()) answers for every live handle and for handles freed with an unread code, in one synchronisation.
 
 # ---- TDVP local contractions (src/solvers/tdvp.jl:29-43, :205-208) ------------------------------------------------------------
 # The five @tensor kernels of tdvp1sweep! / tdvp2sweep!, for Float64 and ComplexF64 arrays in the layouts the sweeps hold
