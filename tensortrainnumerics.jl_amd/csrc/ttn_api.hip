@@ -5,6 +5,7 @@
 #include "ttn_dense_kernels.h"
 #include "ttn_dot_kernels.h"
 #include "ttn_ortho_kernels.h"
+#include "ttn_ortho512.h"
 #include "ttn_hsvd_kernels.h"
 #include "ttn_als_kernels.h"
 #include "ttn_als_grid.h"
@@ -186,6 +187,8 @@ int ttn_init(int device) {
                                (int)COMPRESS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_orthogonalize), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(ORTHO_LDS_BYTES)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ortho512), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(O5_LDS_BYTES(TTN_MAX_D * 8))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dot_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(DOT_LDS_BYTES(DOT_MAX_D))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_selftest_gemm), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1598,6 +1601,18 @@ int ttn_dot(ttn_tt_t a, ttn_tt_t b, double* out) {
     return TTN_OK;
 }
 
+// diagnostics: the per-train state words of the last three-launch orthogonalize (next site, buffers, sites taken by k_ortho512)
+static int* g_ortho_state = nullptr;
+extern "C" int ttn_debug_ortho_state(int64_t b, int64_t* out4) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!g_ortho_state || !out4) return fail(TTN_ERR_ARG, "no three-launch orthogonalize yet");
+    int tmp[4];
+    HIPCHK(hipMemcpyAsync(tmp, g_ortho_state + 4 * b, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (int i = 0; i < 4; ++i) out4[i] = tmp[i];
+    return TTN_OK;
+}
+
 int ttn_last_launch_ms(float* ms) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     NEED_INIT();
@@ -1634,7 +1649,7 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     const long long mm = nmax * rmax;           // rows of the tall matrices
     const long long per_train = 2 * mm * rmax + 4 * rmax * rmax + 2 * QR_NB * mm + ((rmax + QR_NB - 1) / QR_NB) * QR_NB * QR_NB + 64   // Tm, Qb, 4 R, Vb, Wb, T panels
                                 + 3 * 128 * 128;                                                                                  // Gram matrices / L1 of the Cholesky-QR steps
-    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * x->batch);
+    int rc = ensure_scratch(sizeof(double) * (size_t)per_train * x->batch + sizeof(int) * (5 * (size_t)x->batch + 16) + 64);
     if (rc) return rc;
     rc = ensure_batch_bufs(x->batch);
     if (rc) return rc;
@@ -1646,8 +1661,35 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     { const char* e = getenv("TTN_ORTHO_CHOLQR"); P.no_cholqr = e ? (atoi(e) == 0 ? 3 : (atoi(e) == 1 ? 2 : 0)) : 0; }
     P.prof = nullptr;
     if (getenv("TTN_PROF")) { int rcp = ensure_prof(x->batch); if (rcp) return rcp; P.prof = g_prof; }
+    // Large batches of rank <= 64 QTT trains: three launches — the 1024-thread kernel up to the first tall site of the right sweep, the
+    // 512-thread kernel (two workgroups per CU, csrc/ttn_ortho512.h) over the tall sites, the 1024-thread kernel for whatever is left
+    // and the centre core.  TTN_ORTHO512 = 0 / 1 forbids / forces it.
+    bool use512 = x->batch > TTN_NUM_CUS && nmax == 2 && rmax <= 64 && d <= TTN_MAX_D * 8 && center < d;
+    for (int k = 0; k < d; ++k) use512 = use512 && x->dims[k] == 2;
+    { const char* e = getenv("TTN_ORTHO512"); if (e) use512 = atoi(e) != 0 && nmax == 2 && rmax <= 64 && d <= TTN_MAX_D * 8; }
+    P.mode = 0; P.trains = nullptr;
+    P.state = reinterpret_cast<int*>((double*)g_scratch + (size_t)per_train * x->batch);
+    g_ortho_state = P.state;
     HIPCHK(hipEventRecord(g_ev0, g_stream));
-    hipLaunchKernelGGL(k_orthogonalize, dim3(x->batch), dim3(TTN_WG), ORTHO_LDS_BYTES, g_stream, P);
+    if (use512) {
+        P.mode = 1;
+        int* left = P.state + 4 * (size_t)x->batch;                            // count, then the list of trains k_ortho512 did not finish
+        HIPCHK(hipMemsetAsync(left, 0, sizeof(int), g_stream));
+        hipLaunchKernelGGL(k_orthogonalize, dim3(x->batch), dim3(TTN_WG), ORTHO_LDS_BYTES, g_stream, P);
+        hipLaunchKernelGGL(k_ortho512, dim3(x->batch), dim3(O5_WG), O5_LDS_BYTES(d), g_stream, P);
+        // the 512-thread kernel finishes a train (centre core included) unless it had to stop — a refused step, a site outside its
+        // class: the third launch takes only those trains (1024 heavy workgroups cost 4 ms of dispatch even when they do nothing)
+        int h_left = 0;
+        HIPCHK(hipMemcpyAsync(&h_left, left, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        if (h_left > 0) {
+            P.mode = 3;
+            P.trains = left + 1;
+            hipLaunchKernelGGL(k_orthogonalize, dim3(h_left), dim3(TTN_WG), ORTHO_LDS_BYTES, g_stream, P);
+        }
+    } else {
+        hipLaunchKernelGGL(k_orthogonalize, dim3(x->batch), dim3(TTN_WG), ORTHO_LDS_BYTES, g_stream, P);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(g_ev1, g_stream));
     g_have_launch_ms = true;

@@ -13,6 +13,14 @@ struct OrthoArgs {
     double* scratch;
     long long scratch_stride;
     int mmax, rmax;
+    // Three-launch form for large batches of rank <= 64 QTT trains (ttn_api.hip; csrc/ttn_ortho512.h): mode 1 = the left sweep and the
+    // right sweep up to the first site the 512-thread kernel takes, state saved; mode 3 = resume the right sweep from the saved state
+    // with every route, then the centre core; mode 0 = everything in one launch.  state: int [batch][4] = {next right-sweep site,
+    // buffer of the last right R (0: Rc, 1: Rd), buffer of the last left R (0: Rb0, 1: Rb1), train finished by k_ortho512}; behind it one
+    // counter and the list of unfinished trains (int [1 + batch]).
+    int mode;
+    int* state;
+    const int* trains;          // mode 3 only: the trains k_ortho512 did not finish (workgroup w takes train trains[w]); nullptr: b = blockIdx.x
     int no_cholqr;              // bit 0: no Cholesky-QR steps on the general route, bit 1: no fused steps (TTN_ORTHO_CHOLQR = 0 sets both,
                                 // 1 only bit 1: diagnostics, parity tests of every route)
     long long* prof;            // TTN_PROF=1: s_memtime stamp after every QR / LQ step of train b at prof[16 * batch + 120 * b + step] (ttn_prof_steps)
@@ -109,10 +117,15 @@ __device__ void dev_r_and_d_to_rks(int d, const int* dims, const long long* rks,
     }
 }
 
+// the sites csrc/ttn_ortho512.h takes: tall QTT cores of rank <= 64 in the right-to-left sweep (the same test in all three launches)
+__device__ __forceinline__ bool ortho512_eligible(int n, int rl, int rr, int ynext) {
+    return n == 2 && rl <= 64 && rr <= 64 && ynext <= 64 && 2 * ynext > rl;
+}
+
 __global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    const int b = P.trains ? P.trains[blockIdx.x] : blockIdx.x;
     const TTDev& X = P.x; const TTDev& Y = P.y;
     const int d = X.d;
     const long long* xr = X.rks + (long long)b * (d + 1);
@@ -141,16 +154,23 @@ __global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
     Cw.iflag = (int*)(W.Ss + 8);
     Cw.red = red;
     Cw.stamps = P.prof ? P.prof + 136LL * gridDim.x + 64LL * b : nullptr;
-    if (tid == 0) dev_r_and_d_to_rks(d, X.dims, xr, 1024, yr);
+    if (P.prof && tid == 0) P.prof[16LL * gridDim.x + 120LL * b + 100] = (long long)__builtin_amdgcn_s_memtime();
+    if (P.mode != 3 && tid == 0) dev_r_and_d_to_rks(d, X.dims, xr, 1024, yr);
     __syncthreads();
     const int ic = P.center;
+    int* st = P.state ? P.state + 4 * b : nullptr;
+    if (P.mode == 3 && uni32(st[3]) == 1) return;        // k_ortho512 finished this train, centre core included
 
     // ---- left sweep: sites 0..ic-1 (src/tt_tools.jl:518-525) ----
-    if (tid == 0) { Rb0[0] = 1.0; }
+    if (P.mode != 3 && tid == 0) { Rb0[0] = 1.0; }
     __syncthreads();
     View FR = mkview(Rb0, plain(1), plain(1));            // (yr_j x rl)
     int which = 0;
-    for (int j = 0; j < ic; ++j) {
+    if (P.mode == 3) {                                    // the left sweep ran in the mode-1 launch: its last R is in buffer st[2]
+        which = uni32(st[2]);
+        if (ic > 0) FR = mkview(which ? Rb1 : Rb0, plain(1), plain(uni32((int)yr[ic])));      // (which was toggled after the last step)
+    }
+    for (int j = 0; j < ic && P.mode != 3; ++j) {
         const int n = X.dims[j];
         const int yl = uni32((int)yr[j]), rl = uni32((int)xr[j]), rr = uni32((int)xr[j + 1]);
         double* Xj = X.data + (long long)b * X.stride + X.off[j];
@@ -175,13 +195,21 @@ __global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
         which ^= 1;
     }
     // ---- right sweep: sites d-1..ic+1 (src/tt_tools.jl:528-536); its R factors ping-pong in Rc/Rd ----
-    if (tid == 0) { Rc[0] = 1.0; }
+    if (P.mode != 3 && tid == 0) { Rc[0] = 1.0; }
     __syncthreads();
     View FL = mkview(Rc, plain(1), plain(1));             // (rr x yr_{j+1})
     int whichL = 0;
-    for (int j = d - 1; j > ic; --j) {
+    int jstart = d - 1;
+    if (P.mode == 3) {                                    // resume: sites above st[0] are done, their last R is in buffer st[1]
+        jstart = uni32(st[0]);
+        whichL = uni32(st[1]);
+        if (jstart < d - 1) FL = tview(mkview(whichL ? Rd : Rc, plain(1), plain(uni32((int)yr[jstart + 1]))));
+    }
+    int jstop = ic;                                       // (mode 1: the site the 512-thread kernel starts with)
+    for (int j = jstart; j > ic; --j) {
         const int n = X.dims[j];
         const int ynext = uni32((int)yr[j + 1]), rl = uni32((int)xr[j]), rr = uni32((int)xr[j + 1]);
+        if (P.mode == 1 && ortho512_eligible(n, rl, rr, ynext)) { jstop = j; break; }
         double* Xj = X.data + (long long)b * X.stride + X.off[j];
         double* Yj = Y.data + (long long)b * Y.stride + Y.off[j];
         const int mm = ynext * n;
@@ -210,6 +238,12 @@ __global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
         whichL ^= 1;
         if (P.prof && tid == 0 && d - 1 - j < 120) P.prof[16LL * gridDim.x + 120LL * b + (d - 1 - j)] = (long long)__builtin_amdgcn_s_memtime();
     }
+    if (P.mode == 1) {                                    // hand over to k_ortho512 (and then to the mode-3 launch)
+        if (tid == 0) { st[0] = jstop; st[1] = whichL; st[2] = which; st[3] = 0; }
+        return;
+    }
+#define OSTAMP(i) if (P.prof && tid == 0) P.prof[16LL * gridDim.x + 120LL * b + 100 + (i)] = (long long)__builtin_amdgcn_s_memtime();
+    OSTAMP(1)
     // ---- centre core: Y_i[s] = FR * X_i[s] * FL  (src/tt_tools.jl:537-541) ----
     {
         const int n = X.dims[ic];
@@ -220,8 +254,10 @@ __global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
         const View Xv = mkview(Xi, plain(n), Idx{n, 1, (long long)n * rl});
         const View Tv = mkview(Tm, plain(1), Idx{n, (long long)yl, (long long)mm});
         wg_gemm(yl, n * rr, rl, FR, Xv, Tv, 1.0, 0.0, lds);
+        OSTAMP(2)
         const View Tmv = mkview(Tm, plain(1), plain(mm));                               // (mm x rr)
         const View Yv = mkview(Yi, Idx{yl, (long long)n, 1}, plain((long long)n * yl)); // [(al + yl*s), be']
         wg_gemm(mm, yn, rr, Tmv, FL, Yv, 1.0, 0.0, lds);
+        OSTAMP(3)
     }
 }

@@ -283,6 +283,46 @@ def test_orthogonalize_full_size_vs_oracle(T, center):
     assert math.isclose(np.linalg.norm(np.asarray(got.ttv_vec[center - 1])), np.linalg.norm(ref.ttv_vec[center - 1]), rel_tol=1e-12)
 
 
+@pytest.mark.parametrize("d,r,center,seed", [(30, 64, 1, 0), (30, 64, 12, 1), (16, 37, 1, 2), (12, 20, 5, 3), (30, 64, 30, 4), (9, 5, 2, 5)])
+def test_orthogonalize_three_launch_form(T, monkeypatch, d, r, center, seed):
+    """The form large batches of rank <= 64 QTT trains take (csrc/ttn_ortho512.h): the 1024-thread kernel up to the first tall site of
+    the right-to-left sweep, the 512-thread Cholesky-QR kernel (two workgroups per CU) over the tall sites, the 1024-thread kernel
+    for the rest and the centre core — forced here on single trains (TTN_ORTHO512=1) and compared with the oracle: ranks / gauge
+    flags exact, tensor unchanged to 1e-12, every non-centre core orthonormal to 1e-12 (src/tt_tools.jl:511-543); plus a batch of 300
+    trains through the default dispatch (which takes this form above 256 trains)."""
+    rng = np.random.default_rng(500 + seed)
+    x = to_product(O.rand_tt((2,) * d, r, rng))
+    ref = O.orthogonalize(to_oracle(x), i=center)
+    monkeypatch.setenv("TTN_ORTHO512", "1")
+    got = T.orthogonalize(x, i=center)
+    assert got.ttv_rks == ref.ttv_rks and got.ttv_ot == ref.ttv_ot
+    assert tt_rel_diff(to_oracle(got), to_oracle(x)) < 1e-12
+    worst = 0.0
+    for j, G in enumerate(got.ttv_vec):
+        G = np.asarray(G)
+        n, rl, rr = G.shape
+        if j < center - 1:
+            Amat = G.transpose(1, 0, 2).reshape(rl * n, rr, order="F")
+            worst = max(worst, float(np.max(np.abs(Amat.T @ Amat - np.eye(rr)))))
+        elif j > center - 1:
+            Amat = G.transpose(1, 2, 0).reshape(rl, rr * n, order="F")
+            worst = max(worst, float(np.max(np.abs(Amat @ Amat.T - np.eye(rl)))))
+    assert worst < 1e-12, worst
+    monkeypatch.delenv("TTN_ORTHO512")
+    if seed == 2:
+        B = 300
+        dx = T.DeviceTT((2,) * d, x.ttv_rks, batch=B)
+        xs = [to_product(O.rand_tt((2,) * d, r, rng)) for _ in range(4)]
+        for b in range(B):
+            dx.upload(b, xs[b % 4])
+        dy = T.DeviceTT((2,) * d, x.ttv_rks, batch=B)
+        T.device.orthogonalize(dx, center, dy)
+        for b in (0, 1, 150, 299):
+            yb = dy.download(b)
+            assert tt_rel_diff(to_oracle(yb), to_oracle(xs[b % 4])) < 1e-12
+            assert yb.ttv_rks == O.orthogonalize(to_oracle(xs[b % 4]), i=center).ttv_rks
+
+
 # ------------------------------------------------------------------------------------------------
 # _tt_bond_truncate! / tt_compress!
 # ------------------------------------------------------------------------------------------------

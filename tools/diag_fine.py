@@ -7,7 +7,7 @@ import numpy as np
 import ttn_amd as T
 from ttn_amd import device as D
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-d, r = 30, 64
+d, r = int(os.environ.get("TTN_D", 30)), int(os.environ.get("TTN_R", 64))
 T.ensure_init(0)
 A = T.Delta(d); dA = T.DeviceTTO(A)
 x0 = T.rand_tt((2,) * d, r, seed=30)

@@ -29,7 +29,24 @@ for b in sorted({0, B - 1}):
     T._lib.check(L.ttn_prof_steps(b, out))
     st = np.array(out[:d - 1], dtype=np.int64)
     print(f"train {b}: clk per step (sites d .. 2):", np.diff(st).tolist(), "total", int(st[-1] - st[0]))
+    print(f"train {b}: last 1024-thread launch: start -> centre -> first product -> end (clk):", [int(out[101 + i] - out[100 + i]) for i in range(3)])
     ph = (C.c_int64 * 64)()
     T._lib.check(L.ttn_prof_fine(b, ph))
     print("   Cholesky-QR steps (general route), accumulated clk: Gram / load+chol+copy / trsm / Gram check+load / R out:", list(ph[:5]))
     print("   fused steps, accumulated clk: P0 FL image / P1 carry / P2 Gram / P3 Cholesky / P4 inverse / P5 apply / P6 check / P7 R out:", list(ph[8:16]))
+if os.environ.get("TTN_ORTHO512") == "1":
+    import ctypes as C2
+    fn = T._lib.lib().ttn_debug_ortho_state
+    fn.restype = C2.c_int
+    fn.argtypes = [C2.c_int64, C2.POINTER(C2.c_int64)]
+    for b in sorted({0, B - 1}):
+        o = (C2.c_int64 * 4)()
+        fn(b, o)
+        print(f"train {b}: three-launch state [next site, right buffer, left buffer, sites taken by k_ortho512] = {list(o)}")
+    notdone = []
+    for b in range(B):
+        o = (C2.c_int64 * 4)()
+        fn(b, o)
+        if o[3] != 1:
+            notdone.append((b, list(o)))
+    print(f"trains k_ortho512 did not finish: {len(notdone)} of {B}", notdone[:8])
