@@ -6,6 +6,7 @@
 #include "ttn_dot_kernels.h"
 #include "ttn_ortho_kernels.h"
 #include "ttn_ortho512.h"
+#include "ttn_ortho_ramp.h"
 #include "ttn_hsvd_kernels.h"
 #include "ttn_als_kernels.h"
 #include "ttn_als_grid.h"
@@ -1667,7 +1668,7 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     bool use512 = x->batch > TTN_NUM_CUS && nmax == 2 && rmax <= 64 && d <= TTN_MAX_D * 8 && center < d;
     for (int k = 0; k < d; ++k) use512 = use512 && x->dims[k] == 2;
     { const char* e = getenv("TTN_ORTHO512"); if (e) use512 = atoi(e) != 0 && nmax == 2 && rmax <= 64 && d <= TTN_MAX_D * 8; }
-    P.mode = 0; P.trains = nullptr;
+    P.mode = 0; P.trains = nullptr; P.ramp = 0;
     P.state = reinterpret_cast<int*>((double*)g_scratch + (size_t)per_train * x->batch);
     g_ortho_state = P.state;
     HIPCHK(hipEventRecord(g_ev0, g_stream));
@@ -1675,7 +1676,14 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
         P.mode = 1;
         int* left = P.state + 4 * (size_t)x->batch;                            // count, then the list of trains k_ortho512 did not finish
         HIPCHK(hipMemsetAsync(left, 0, sizeof(int), g_stream));
-        hipLaunchKernelGGL(k_orthogonalize, dim3(x->batch), dim3(TTN_WG), ORTHO_LDS_BYTES, g_stream, P);
+        // the ramp sites at the right end (wide / square LQ steps) go to one wave per train (csrc/ttn_ortho_ramp.h); the 1024-thread
+        // kernel then only runs the left sweep, and not at all when the centre is the first site.  TTN_ORTHO_RAMP = 0: without.
+        { const char* e = getenv("TTN_ORTHO_RAMP"); P.ramp = e ? (atoi(e) != 0) : 1; }
+        if (!P.ramp || P.center > 0) hipLaunchKernelGGL(k_orthogonalize, dim3(x->batch), dim3(TTN_WG), ORTHO_LDS_BYTES, g_stream, P);
+        if (P.ramp) {
+            P.mode = P.center > 0 ? 4 : 5;
+            hipLaunchKernelGGL(k_ortho_ramp, dim3((x->batch + ORAMP_WG / 64 - 1) / (ORAMP_WG / 64)), dim3(ORAMP_WG), 0, g_stream, P, (int)x->batch);
+        }
         hipLaunchKernelGGL(k_ortho512, dim3(x->batch), dim3(O5_WG), O5_LDS_BYTES(d), g_stream, P);
         // the 512-thread kernel finishes a train (centre core included) unless it had to stop — a refused step, a site outside its
         // class: the third launch takes only those trains (1024 heavy workgroups cost 4 ms of dispatch even when they do nothing)

@@ -20,6 +20,7 @@ struct OrthoArgs {
     // counter and the list of unfinished trains (int [1 + batch]).
     int mode;
     int* state;
+    int ramp;                   // mode 1 only: stop the right sweep at its first site (k_ortho_ramp, csrc/ttn_ortho_ramp.h, takes it from there)
     const int* trains;          // mode 3 only: the trains k_ortho512 did not finish (workgroup w takes train trains[w]); nullptr: b = blockIdx.x
     int no_cholqr;              // bit 0: no Cholesky-QR steps on the general route, bit 1: no fused steps (TTN_ORTHO_CHOLQR = 0 sets both,
                                 // 1 only bit 1: diagnostics, parity tests of every route)
@@ -209,7 +210,7 @@ __global__ void TTN_KERNEL_BOUNDS k_orthogonalize(OrthoArgs P) {
     for (int j = jstart; j > ic; --j) {
         const int n = X.dims[j];
         const int ynext = uni32((int)yr[j + 1]), rl = uni32((int)xr[j]), rr = uni32((int)xr[j + 1]);
-        if (P.mode == 1 && ortho512_eligible(n, rl, rr, ynext)) { jstop = j; break; }
+        if (P.mode == 1 && (P.ramp || ortho512_eligible(n, rl, rr, ynext))) { jstop = j; break; }
         double* Xj = X.data + (long long)b * X.stride + X.off[j];
         double* Yj = Y.data + (long long)b * Y.stride + Y.off[j];
         const int mm = ynext * n;
