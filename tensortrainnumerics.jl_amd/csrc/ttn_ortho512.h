@@ -142,8 +142,12 @@ __device__ __forceinline__ void o5_apply(const mfma_acc_t (&src_)[4], mfma_acc_t
 // (out of line on purpose: inlined twice into the kernel's site loop the two instantiations cost 356 spilled VGPRs)
 template <bool FULL>
 __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, const double* Rprev, double* Rn, int rl, int rr, int ynext,
-                                    int cur, int first, long long* yr_j) {
-    lds = unip(lds); Xj = unip(Xj); Yj = unip(Yj); Rprev = unip(Rprev); Rn = unip(Rn); yr_j = unip(yr_j);
+                                    int cur, int first, long long* yr_j, long long* stamps) {
+    lds = unip(lds); Xj = unip(Xj); Yj = unip(Yj); Rprev = unip(Rprev); Rn = unip(Rn); yr_j = unip(yr_j); stamps = unip(stamps);
+    // TTN_PROF: clocks accumulated per phase (slots: 0 images / 1 carry + Gram / 2 dmax + padding / 3 Cholesky / 4 inverse / 5 apply /
+    // 6 measured check / 7 second passes / 8 stores)
+    long long t_prev = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define O5S(i) if (stamps) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) stamps[i] += now_ - t_prev; t_prev = now_; }
     rl = uni32(rl); rr = uni32(rr); ynext = uni32(ynext); cur = uni32(cur); first = uni32(first);
     lds_f64* buf = (lds_f64*)lds;
     lds_f64* T16 = (lds_f64*)lds + O5_T16;
@@ -160,6 +164,7 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
     }
     if (tid == 0) { flag[0] = 0; ((__attribute__((address_space(3))) unsigned long long*)misc)[1] = 0ull; }
     __syncthreads();
+    O5S(0)
     lds_f64* FLb = buf + cur * O5_BUF;
     lds_f64* Gb = buf + (cur ^ 1) * O5_BUF;
     // ---- P1: W_w[be][al] = sum_ga FL[ga][be] X_j[s, al, ga] ----
@@ -201,6 +206,7 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
         o5_gram_add<FULL>(w_, nat, Gb);
     }
     __syncthreads();
+    O5S(1)
     // ---- P3: dmax, padding, the FL image becomes the (zeroed) L^-1 image, blocked Cholesky ----
     if (wave == 0) {
         double dm = 0.0;
@@ -217,6 +223,7 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
         for (int i = rl + tid; i < 16 * nat; i += O5_WG) Gb[O5_IMG(i, i)] = dmax;
         __syncthreads();
         lds_f64* Li = FLb;
+        O5S(2)
         for (int jb = 0; jb < nat && good; ++jb) {
             if (wave == 0) { if (!o5_diag_block(jb, Gb, T16, Li, dmin) && lane == 0) flag[0] = 1; }
             __syncthreads();
@@ -252,6 +259,7 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
             }
             __syncthreads();
         }
+        O5S(3)
         // ---- P4: off-diagonal blocks of X = L^-1 ----
         for (int lev = 1; lev < nat && good; ++lev) {
             const int ib = lev + wave, jbk = wave;
@@ -275,9 +283,11 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
         }
     }
     if (!good) return 0;                                            // refused: Rprev in global memory is intact, the state stays at site j
+    O5S(4)
     // ---- P5: Q_w[rho][al'] = sum_{al <= al'} W_w[rho][al] X[al'][al]; A fragments = W tiles transposed by ds_bpermute ----
     mfma_acc_t q_[4];
     o5_apply<FULL>(w_, q_, FLb, nat, tr < nbt);
+    O5S(5)
     // ---- P6: the orthogonality of Q, measured: max |Q^T Q - I| over the lower triangle (the image that held L^-1 takes Q^T Q) ----
     auto measure = [&]() -> double {
         __syncthreads();                                                // every read of the image (L^-1 / X2) is done
@@ -297,6 +307,7 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
         return unif64(__longlong_as_double((long long)((__attribute__((address_space(3))) unsigned long long*)misc)[1]));
     };
     double devmax = measure();
+    O5S(6)
     for (int pass = 0; !(devmax <= ORTHO_FUSED_ACCEPT); ++pass) {
         if (!(devmax <= O5_POLISH_MAX) || pass == 3) return 0;
         const bool recheck = devmax > O5_POLISH_TRUST;
@@ -332,6 +343,7 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
         if (!recheck) break;                                            // E <= 1e-9: the pass leaves O(64 E^2) <= 1e-16, not measured again
         devmax = measure();
     }
+    O5S(7)
     // ---- P7: Y_j, R = L^T to global memory, the check image zeroed for the next G ----
     if (tr < nbt) {
         typedef __attribute__((address_space(1))) double gwd;
@@ -349,6 +361,7 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
     for (int e = tid; e < O5_BUF; e += O5_WG) FLb[e] = 0.0;
     if (tid == 0) *yr_j = rl;
     __syncthreads();
+    O5S(8)
     return 1;                                                               // (the caller flips the images: this step's L is the next step's FL)
 }
 
@@ -368,6 +381,7 @@ __global__ void __launch_bounds__(O5_WG, 4) k_ortho512(OrthoArgs P) {
     lds_f64* T16 = (lds_f64*)lds + O5_T16;
     lds_f64* misc = (lds_f64*)lds + O5_MISC;
     lds_i32* flag = (lds_i32*)misc;
+    long long* stamps = P.prof ? P.prof + 136LL * gridDim.x + 64LL * b + 16 : nullptr;
     lds_i32* tab = (lds_i32*)((lds_f64*)lds + O5_TAB);
     for (int k = tid; k <= d; k += O5_WG) {
         tab[4 * k + 0] = (int)xr[k];
@@ -391,8 +405,8 @@ __global__ void __launch_bounds__(O5_WG, 4) k_ortho512(OrthoArgs P) {
         double* Rn = whichL ? Rc : Rd;
         const bool full = rl == 64 && rr == 64 && ynext == 64;
         if (first) cur = 0;
-        const int ok = full ? o5_step<true>(lds, Xj, Yj, Rprev, Rn, rl, rr, ynext, cur, first ? 1 : 0, yr + j)
-                            : o5_step<false>(lds, Xj, Yj, Rprev, Rn, rl, rr, ynext, cur, first ? 1 : 0, yr + j);
+        const int ok = full ? o5_step<true>(lds, Xj, Yj, Rprev, Rn, rl, rr, ynext, cur, first ? 1 : 0, yr + j, stamps)
+                            : o5_step<false>(lds, Xj, Yj, Rprev, Rn, rl, rr, ynext, cur, first ? 1 : 0, yr + j, stamps);
         first = false;
         if (!ok) break;
         cur ^= 1;

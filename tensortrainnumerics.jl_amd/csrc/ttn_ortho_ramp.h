@@ -7,7 +7,7 @@
 // 64 dependent column steps, each a norm, a rank-one update and several barriers when a 1024-thread workgroup runs it (650 k clk for
 // the six ramp sites of a rank-64 train, one train per CU: 1.4 ms of the 5.9 ms a batch of 1024 takes).  A wave needs no barriers:
 //   * lane c holds COLUMN c of the site's matrix W (rows i = 2 be + s in registers a[0 .. ROWS-1]);
-//   * the reflector of step k lives in lane k: v_i = readlane(a[i], k) is a scalar, the rank-one update is two FMAs per row;
+//   * the reflector of step k lives in lane k: x_i = readlane(a[i], k) is a scalar, the rank-one update is two FMAs per row;
 //   * the R factor stays in registers for the next site's carry product  W'[2 be + s][al] = sum_ga R[be][ga] X'[s, al, ga]
 //     (again readlane scalars times per-lane 16-byte loads of X');
 //   * Q is formed in place from the stored reflectors (the dorg2r recurrence) and written as the core Y_j.
@@ -29,14 +29,95 @@ __device__ __forceinline__ bool ortho_ramp_eligible(int n, int rl, int rr, int y
     return n == 2 && rl <= 64 && rr <= 64 && 2 * ynext <= rl;
 }
 
+// Householder steps k in [kbeg, kend) of the phase whose rows start at LO (k lies in rows LO .. LO + CH - 1: rows below LO are finished and
+// are not touched, rows from LO + CH on are below every k of the phase and need no masks).  The reflector is kept UNSCALED:
+// H = I - t u u^T, u = x - beta e_k, t = -1 / (beta u_k): the dot products with x need neither beta nor a stored copy of x — every
+// x_i is a readlane scalar used on the spot (two passes over the rows, no uniform array, no SGPR spills).
+template <int ROWS, int LO, int CH>
+__device__ __forceinline__ void oramp_fwd_phase(double (&a)[ROWS], double& tauv, double& ukv, int kbeg, int kend) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int kk = kbeg; kk < kend; ++kk) {
+        const int k = __builtin_amdgcn_readfirstlane(kk);
+        double xk = 0.0, ak = 0.0;
+        double n0 = 0.0, n1 = 0.0, d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int i = LO; i < ROWS; ++i) {
+            double xi = oramp_readlane(a[i], k);
+            if (i < LO + CH) {
+                xk = (i == k) ? xi : xk;
+                ak = (i == k) ? a[i] : ak;
+                xi = (i > k) ? xi : 0.0;
+            }
+            if (i & 1) { n1 = fma(xi, xi, n1); d1 = fma(xi, a[i], d1); }
+            else       { n0 = fma(xi, xi, n0); d0 = fma(xi, a[i], d0); }
+        }
+        const double nrm2 = n0 + n1;
+        if (nrm2 == 0.0) continue;                                        // H = I: the column is already in its final form (t stays 0)
+        const double beta = -copysign(sqrt(fma(xk, xk, nrm2)), xk);
+        const double uk = xk - beta;
+        const double t = -1.0 / (beta * uk);
+        const bool mine = lane == k;
+        const double ts = (lane > k) ? t * fma(uk, ak, d0 + d1) : 0.0;    // (the lanes left of k hold finished columns and their reflectors)
+#pragma unroll
+        for (int i = LO; i < ROWS; ++i) {
+            const double xi = oramp_readlane(a[i], k);
+            if (i < LO + CH) {
+                const double ui = (i > k) ? xi : ((i == k) ? uk : 0.0);
+                const double u = fma(-ts, ui, a[i]);
+                a[i] = (mine && i == k) ? beta : u;
+            } else {
+                a[i] = fma(-ts, xi, a[i]);                                // (lane k: ts = 0, its rows below the diagonal keep u_i = x_i)
+            }
+        }
+        tauv = mine ? t : tauv;
+        ukv = mine ? uk : ukv;
+    }
+}
+
+// Q = H_0 H_1 ... in place (the dorg2r recurrence), steps k = kend - 1 .. kbeg of the phase whose rows start at LO.  Lane k turns its
+// reflector into column k (e_k - t u_k u), the lanes right of it take H_k.
+template <int ROWS, int LO, int CH>
+__device__ __forceinline__ void oramp_bwd_phase(double (&a)[ROWS], double tauv, double ukv, int kbeg, int kend, int rows) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int kk = kend - 1; kk >= kbeg; --kk) {
+        const int k = __builtin_amdgcn_readfirstlane(kk);
+        const double t = oramp_readlane(tauv, k), uk = oramp_readlane(ukv, k);
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = LO; i < ROWS; ++i) {
+            double xi = oramp_readlane(a[i], k);
+            if (i < LO + CH) xi = (i > k) ? xi : 0.0;
+            if (i & 1) s1 = fma(xi, a[i], s1); else s0 = fma(xi, a[i], s0);
+        }
+        const bool mine = lane == k;
+        const double w = -t * uk;
+        const double ts = (lane > k && lane < rows) ? t * (s0 + s1) : 0.0;
+        const double cf = mine ? w - 1.0 : -ts;                           // lane k: a[i] = x_i, so a[i] + (w - 1) x_i = w x_i
+#pragma unroll
+        for (int i = LO; i < ROWS; ++i) {
+            const double xi = oramp_readlane(a[i], k);
+            if (i < LO + CH) {
+                const double ui = (i > k) ? xi : 0.0;
+                const double u = fma(cf, ui, a[i]);
+                a[i] = (i == k) ? (mine ? fma(w, uk, 1.0) : fma(-ts, uk, a[i])) : u;
+            } else {
+                a[i] = fma(cf, xi, a[i]);
+            }
+        }
+    }
+}
+
 // One site.  In: Rp[be] (lane ga) = FL[ga][be] for be < ROWS / 2 (zero beyond ynext and beyond rr).  Out: Y_j, R to Rn (ld = rows),
-// Rp = this site's R for the next one (when ROWS <= 32), rows = 2 ynext returned through the caller's bookkeeping.
+// Rp = this site's R for the next one (when ROWS <= 32).
 template <int ROWS>
 __device__ __forceinline__ void oramp_site(double (&Rp)[32], const double* __restrict__ Xj, double* __restrict__ Yj, double* __restrict__ Rn,
                                            int rl, int rr, int ynext) {
     const int lane = threadIdx.x & 63;
     const int rows = 2 * ynext;
     constexpr int HB = ROWS / 2;
+    constexpr int CH = ROWS < 16 ? ROWS : 16;
     double a[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) a[i] = 0.0;
@@ -59,37 +140,13 @@ __device__ __forceinline__ void oramp_site(double (&Rp)[32], const double* __res
         }
     }
     // ---- Householder steps k = 0 .. rows - 2 (the last row needs none); the reflector of step k stays in lane k below the diagonal ----
-    double tauv = 0.0;
-#pragma unroll 1
-    for (int kk = 0; kk < rows - 1; ++kk) {
-        const int k = __builtin_amdgcn_readfirstlane(kk);
-        double v[ROWS];
-        double xk = 0.0, nrm2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            const double xi = oramp_readlane(a[i], k);
-            v[i] = (i > k) ? xi : 0.0;
-            xk = (i == k) ? xi : xk;
-            nrm2 = fma(v[i], v[i], nrm2);
-        }
-        if (nrm2 == 0.0) continue;                                        // H = I (tau = 0): the column is already in its final form
-        const double beta = -copysign(sqrt(fma(xk, xk, nrm2)), xk);
-        const double tau = (beta - xk) / beta;
-        const double scale = 1.0 / (xk - beta);
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            v[i] = (i == k) ? 1.0 : v[i] * scale;
-            s = fma(v[i], a[i], s);
-        }
-        const double ts = (lane > k) ? tau * s : 0.0;                     // (the lanes left of k hold finished columns and their reflectors)
-        const bool mine = lane == k;
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            const double u = fma(-ts, v[i], a[i]);
-            a[i] = mine ? ((i > k) ? v[i] : ((i == k) ? beta : a[i])) : u;
-        }
-        tauv = mine ? tau : tauv;
+    double tauv = 0.0, ukv = 0.0;
+    const int klast = rows - 1;
+    oramp_fwd_phase<ROWS, 0, CH>(a, tauv, ukv, 0, klast < CH ? klast : CH);
+    if constexpr (ROWS > 16) oramp_fwd_phase<ROWS, 16, CH>(a, tauv, ukv, 16, klast < 32 ? klast : 32);
+    if constexpr (ROWS > 32) {
+        oramp_fwd_phase<ROWS, 32, CH>(a, tauv, ukv, 32, klast < 48 ? klast : 48);
+        oramp_fwd_phase<ROWS, 48, CH>(a, tauv, ukv, 48, klast);
     }
     // ---- R (rows x rl, upper trapezoid) to global memory and to the registers the next site's carry reads ----
     {
@@ -105,27 +162,12 @@ __device__ __forceinline__ void oramp_site(double (&Rp)[32], const double* __res
     // ---- Q (rows x rows) in place: columns k = rows - 1 .. 0; column c > k already holds a column of H_{k+1} ... H_{rows-2} ----
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) a[i] = (i <= lane || lane >= rows) ? ((i == lane && lane == rows - 1) ? 1.0 : 0.0) : a[i];
-#pragma unroll 1
-    for (int kk = rows - 2; kk >= 0; --kk) {
-        const int k = __builtin_amdgcn_readfirstlane(kk);
-        const double tau = oramp_readlane(tauv, k);
-        double v[ROWS];
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            const double xi = oramp_readlane(a[i], k);
-            v[i] = (i > k) ? xi : ((i == k) ? 1.0 : 0.0);
-            s = fma(v[i], a[i], s);
-        }
-        const bool upd = lane > k && lane < rows;
-        const bool mine = lane == k;
-        const double ts = upd ? tau * s : 0.0;
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-            const double u = fma(-ts, v[i], a[i]);
-            a[i] = mine ? ((i > k) ? -tau * v[i] : ((i == k) ? 1.0 - tau : 0.0)) : u;
-        }
+    if constexpr (ROWS > 32) {
+        oramp_bwd_phase<ROWS, 48, CH>(a, tauv, ukv, 48, klast, rows);
+        oramp_bwd_phase<ROWS, 32, CH>(a, tauv, ukv, 32, klast < 48 ? klast : 48, rows);
     }
+    if constexpr (ROWS > 16) oramp_bwd_phase<ROWS, 16, CH>(a, tauv, ukv, 16, klast < 32 ? klast : 32, rows);
+    oramp_bwd_phase<ROWS, 0, CH>(a, tauv, ukv, 0, klast < CH ? klast : CH, rows);
     // ---- Y_j[s, al' = lane, be] = Q[2 be + s][al']: the two s of a (be, al') are one 16-byte store ----
     if (lane < rows) {
         typedef double __attribute__((ext_vector_type(2))) d2;
