@@ -228,6 +228,25 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
             if (wave == 0) { if (!o5_diag_block(jb, Gb, T16, Li, dmin) && lane == 0) flag[0] = 1; }
             __syncthreads();
             if (uni32(flag[0])) { good = false; break; }
+            if (wave >= 4 && wave - 4 < jb) {
+                // row jb of X = L^-1 in the shadow of the panel (waves 1 .. 3): X[jb][c] = -X[jb][jb] sum_{kb = c}^{jb-1} L[jb][kb] X[kb][c].
+                // L's block row jb is final since the panel of step jb - 1, the rows of X above since their own steps.
+                const int ib = jb, jbk = wave - 4;
+                mfma_acc_t s_ = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+                for (int kb = jbk; kb < ib; ++kb) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int kk = 4 * t + lk;                    // S[row][col] += L[16 ib + row][16 kb + kk] X[16 kb + kk][16 jbk + col]
+                        s_ = __builtin_amdgcn_mfma_f64_16x16x4f64(Gb[O5_IMG(16 * kb + kk, 16 * ib + li)], Li[O5_IMG(16 * jbk + li, 16 * kb + kk)], s_, 0, 0, 0);
+                    }
+                }
+                mfma_acc_t x_ = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)                          // X_ij[row][col] = -sum_m X_ii[row][m] S[m][col]: S's registers are the B operand
+                    x_ = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[O5_IMG(16 * ib + 4 * r + lk, 16 * ib + li)], s_[r], x_, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Li[O5_IMG(16 * jbk + li, 16 * ib + lk + 4 * reg)] = -x_[reg];
+            }
             if (wave >= 1 && jb + wave < nat) {                         // panel: L[ib][jb] = G[ib][jb] X_jj^T
                 const int ib = jb + wave;
                 mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
@@ -260,27 +279,6 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
             __syncthreads();
         }
         O5S(3)
-        // ---- P4: off-diagonal blocks of X = L^-1 ----
-        for (int lev = 1; lev < nat && good; ++lev) {
-            const int ib = lev + wave, jbk = wave;
-            if (ib < nat) {
-                mfma_acc_t s_ = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
-                for (int kb = jbk; kb < ib; ++kb) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int kk = 4 * t + lk;                    // S[row][col] += L[16 ib + row][16 kb + kk] X[16 kb + kk][16 jbk + col]
-                        s_ = __builtin_amdgcn_mfma_f64_16x16x4f64(Gb[O5_IMG(16 * kb + kk, 16 * ib + li)], Li[O5_IMG(16 * jbk + li, 16 * kb + kk)], s_, 0, 0, 0);
-                    }
-                }
-                mfma_acc_t x_ = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r)                          // X_ij[row][col] = -sum_m X_ii[row][m] S[m][col]
-                    x_ = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[O5_IMG(16 * ib + 4 * r + lk, 16 * ib + li)], s_[r], x_, 0, 0, 0);
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Li[O5_IMG(16 * jbk + li, 16 * ib + lk + 4 * reg)] = -x_[reg];
-            }
-            __syncthreads();
-        }
     }
     if (!good) return 0;                                            // refused: Rprev in global memory is intact, the state stays at site j
     O5S(4)
