@@ -33,46 +33,49 @@ __device__ __forceinline__ void o5_barrier() { __syncthreads(); }
 
 // diagonal block jb: factor and invert in registers (as of_diag_block, on the swizzled image; Linv -> T16 and the Linv image)
 __device__ __forceinline__ bool o5_diag_block(int jb, lds_f64* G, lds_f64* T16, lds_f64* Li, double dmin) {
-    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    int lane = threadIdx.x & 63;
+    // (opaque to the compiler: it hoisted the sixteen identity columns (li == jj ? 1 : 0) and the LDS addresses of this block out of the
+    //  caller's loop over the diagonal blocks as loop invariants, spilled them, and reloaded one from scratch memory in every step — a
+    //  memory latency in each link of the block's dependent chain: 9.1 k clk per block, measured)
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
     double e[16], t[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) e[c] = G[O5_IMG(16 * jb + c, 16 * jb + li)];
     double dinv = 1.0;
     bool ok = true;
+    // Factor and inverse in ONE loop.  Step jj of the factorisation finishes column jj of L; with it the elimination step jj of
+    // U'^-1 (L = U' D, U'[i][k] = L[i][k] / L[k][k]) can run at once — its row jj is final, its multipliers are L[li][jj] rs_jj — so the
+    // 15 - jj updates of the factor and the jj + 1 updates of the inverse are sixteen INDEPENDENT DPP FMAs per step (the two loops one
+    // after the other were two dependent chains: 9.1 k clk per block, measured).  X = D^-1 U'^-1: one scaling at the end.
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const double d = of_readlane(e[jj], jj);
         ok = ok && (d > dmin);
         const double rs = fast_rsqrt2(d);
         const double l = e[jj] * rs;
-        e[jj] = l;
+        // (column jj of L is final: to the image now — with the columns of the inverse that are still the identity not yet in registers,
+        //  17 doubles are live per step instead of 32; with 32 the compiler spilled, and the reload in every step was the block's time)
+        if (lk == 0) G[O5_IMG(16 * jb + jj, 16 * jb + li)] = (jj <= li) ? l : 0.0;
+        t[jj] = (li == jj) ? 1.0 : 0.0;
         dinv = (li == jj) ? rs : dinv;
         const double nl = -l;
+        const double s_ = (li > jj) ? nl * rs : 0.0;                       // -L[li][jj] / L[jj][jj]
         OF_DPP_FENCE();
 #define O5_UPD(C) if (C > jj) of_fmac_bcast<C>(e[C], l, nl);
+#define O5_INV(K) if (jj == K) { _Pragma("unroll") for (int c = 0; c < 16; ++c) if (c <= K) of_fmac_bcast<K>(t[c], t[c], s_); }
         O5_UPD(1) O5_UPD(2) O5_UPD(3) O5_UPD(4) O5_UPD(5) O5_UPD(6) O5_UPD(7) O5_UPD(8) O5_UPD(9) O5_UPD(10) O5_UPD(11) O5_UPD(12) O5_UPD(13) O5_UPD(14) O5_UPD(15)
+        O5_INV(0) O5_INV(1) O5_INV(2) O5_INV(3) O5_INV(4) O5_INV(5) O5_INV(6) O5_INV(7) O5_INV(8) O5_INV(9) O5_INV(10) O5_INV(11) O5_INV(12) O5_INV(13) O5_INV(14)
 #undef O5_UPD
+#undef O5_INV
         OF_DPP_FENCE();
     }
     if (!ok) return false;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) t[c] = (c == li) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) if (c <= k) t[c] = (li == k) ? t[c] * dinv : t[c];
-        if (k < 15) {
-            const double s_ = (li > k) ? -e[k] : 0.0;
-            OF_DPP_FENCE();
-#define O5_INV(K) if (k == K) { _Pragma("unroll") for (int c = 0; c < 16; ++c) if (c <= K) of_fmac_bcast<K>(t[c], t[c], s_); }
-            O5_INV(0) O5_INV(1) O5_INV(2) O5_INV(3) O5_INV(4) O5_INV(5) O5_INV(6) O5_INV(7) O5_INV(8) O5_INV(9) O5_INV(10) O5_INV(11) O5_INV(12) O5_INV(13) O5_INV(14)
-#undef O5_INV
-        }
-    }
+    for (int c = 0; c < 16; ++c) t[c] *= dinv;
     if (lk == 0) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            G[O5_IMG(16 * jb + c, 16 * jb + li)] = (c <= li) ? e[c] : 0.0;              // L, the strict upper triangle of the block zeroed
+        for (int c = 0; c < 16; ++c) {                                                  // (L went to the image column by column, its strict upper triangle zeroed)
             T16[li * 17 + c] = (c <= li) ? t[c] : 0.0;
             Li[O5_IMG(16 * jb + c, 16 * jb + li)] = (c <= li) ? t[c] : 0.0;             // L^-1[row][col] as element (row, col)
         }
@@ -226,7 +229,9 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
         O5S(2)
         for (int jb = 0; jb < nat && good; ++jb) {
             if (wave == 0) { if (!o5_diag_block(jb, Gb, T16, Li, dmin) && lane == 0) flag[0] = 1; }
+            O5S(9)
             __syncthreads();
+            O5S(10)
             if (uni32(flag[0])) { good = false; break; }
             if (wave >= 4 && wave - 4 < jb) {
                 // row jb of X = L^-1 in the shadow of the panel (waves 1 .. 3): X[jb][c] = -X[jb][jb] sum_{kb = c}^{jb-1} L[jb][kb] X[kb][c].
@@ -259,7 +264,9 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
                 for (int reg = 0; reg < 4; ++reg) Gb[O5_IMG(16 * jb + li, 16 * ib + lk + 4 * reg)] = acc[reg];
             }
             // (the blocks above the diagonal were never added to — only lower tiles are — so L's upper triangle is zero: it is the next FL)
+            O5S(11)
             __syncthreads();
+            O5S(12)
             {
                 const int nrem = nat - jb - 1, ntile = nrem * (nrem + 1) / 2;
                 for (int tile = wave; tile < ntile; tile += 8) {

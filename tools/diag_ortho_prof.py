@@ -35,6 +35,7 @@ for b in sorted({0, B - 1}):
     print("   Cholesky-QR steps (general route), accumulated clk: Gram / load+chol+copy / trsm / Gram check+load / R out:", list(ph[:5]))
     print("   fused steps, accumulated clk: P0 FL image / P1 carry / P2 Gram / P3 Cholesky / P4 inverse / P5 apply / P6 check / P7 R out:", list(ph[8:16]))
     print("   k_ortho512 steps, accumulated clk: images / carry+Gram / dmax+padding / Cholesky / inverse / apply / check / second passes / stores:", list(ph[16:25]), "sum", sum(ph[16:25]))
+    print("      inside Cholesky: diag block / barrier / panel + X row / barrier (then trailing + barrier = the rest):", list(ph[25:29]))
 if os.environ.get("TTN_ORTHO512") == "1":
     import ctypes as C2
     fn = T._lib.lib().ttn_debug_ortho_state
