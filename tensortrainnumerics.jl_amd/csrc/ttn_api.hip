@@ -1662,12 +1662,12 @@ int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y) {
     { const char* e = getenv("TTN_ORTHO_CHOLQR"); P.no_cholqr = e ? (atoi(e) == 0 ? 3 : (atoi(e) == 1 ? 2 : 0)) : 0; }
     P.prof = nullptr;
     if (getenv("TTN_PROF")) { int rcp = ensure_prof(x->batch); if (rcp) return rcp; P.prof = g_prof; }
-    // Batches of rank <= 64 QTT trains: the ramp sites at the right end by one wave per train (csrc/ttn_ortho_ramp.h), the tall sites
-    // and the centre core by the 512-thread kernel (two workgroups per CU, csrc/ttn_ortho512.h), the 1024-thread kernel before them for
-    // the left sweep and after them only for the trains they did not finish.  Measured against the single launch (d = 30, rank 64):
-    // 1.47 vs 1.58 ms at 16 trains, 1.77 vs 2.06 at 256, 4.76 vs 7.52 at 1024; a single train is 5 % slower (the host reads one word
-    // between the launches).  TTN_ORTHO512 = 0 / 1 forbids / forces it.
-    bool use512 = x->batch >= 16 && nmax == 2 && rmax <= 64 && d <= TTN_MAX_D * 8 && center < d;
+    // Rank <= 64 QTT trains: the ramp sites at the right end by one wave per train (csrc/ttn_ortho_ramp.h), the tall sites and the
+    // centre core by the 512-thread kernel (two workgroups per CU, csrc/ttn_ortho512.h), the 1024-thread kernel before them for the
+    // left sweep and after them only for the trains they did not finish.  Measured against the single launch (d = 30, rank 64, centre
+    // 1): 1.24 vs 1.28 ms for one train, 1.28 vs 1.48 at 8, 1.41 vs 1.89 at 256, 3.36 vs 6.89 at 1024.  TTN_ORTHO512 = 0 / 1 forbids /
+    // forces it.
+    bool use512 = nmax == 2 && rmax <= 64 && d <= TTN_MAX_D * 8 && center < d;
     for (int k = 0; k < d; ++k) use512 = use512 && x->dims[k] == 2;
     { const char* e = getenv("TTN_ORTHO512"); if (e) use512 = atoi(e) != 0 && nmax == 2 && rmax <= 64 && d <= TTN_MAX_D * 8; }
     P.mode = 0; P.trains = nullptr; P.ramp = 0;

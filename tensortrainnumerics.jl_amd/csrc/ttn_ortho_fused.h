@@ -57,47 +57,47 @@ __device__ __forceinline__ double of_readlane(double v, int idx) {
 // Every 16-lane row of the wave holds the whole block: lane li = row li, e[c] = D[li][c] (the four rows compute the same).
 // Returns false on a pivot <= dmin.  Writes L to the image (lower triangle) and X to T16[row * 17 + col] and to the L^-1 image.
 __device__ __forceinline__ bool of_diag_block(int jb, lds_f64* G, lds_f64* T16, lds_f64* Li, double dmin) {
-    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    int lane = threadIdx.x & 63;
+    // (opaque to the compiler: it hoists the identity columns (li == jj ? 1 : 0) and the LDS addresses of this block out of the caller's
+    //  loop over the diagonal blocks, spills them and reloads one from scratch memory in every step of the dependent chain below)
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
     double e[16], t[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) e[c] = G[OF_G(16 * jb + li, 16 * jb + c)];
     double dinv = 1.0;
     bool ok = true;
+    // Factor and inverse in one loop: step jj of the factorisation finishes column jj of L, and with it the elimination step jj of
+    // U'^-1 (L = U' D, U'[i][k] = L[i][k] / L[k][k]) can run — its row jj is final, its multipliers are -L[li][jj] rs_jj: 15 - jj updates
+    // of the factor and jj + 1 of the inverse, independent of each other.  X = D^-1 U'^-1: one scaling at the end.  Column jj of L goes
+    // to the image as soon as it is final and the columns of the inverse enter the registers when they stop being the identity:
+    // 17 doubles live per step.
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const double d = of_readlane(e[jj], jj);
         ok = ok && (d > dmin);                                           // wave-uniform; no early exit: the loop must unroll (e[] stays in registers)
         const double rs = fast_rsqrt2(d);
         const double l = e[jj] * rs;                                     // L[li][jj] (li >= jj); sqrt(d) on the diagonal
-        e[jj] = l;
+        if (lk == 0 && jj <= li) G[OF_G(16 * jb + li, 16 * jb + jj)] = l;
+        t[jj] = (li == jj) ? 1.0 : 0.0;
         dinv = (li == jj) ? rs : dinv;                                   // 1 / L[li][li]
         const double nl = -l;
+        const double s_ = (li > jj) ? nl * rs : 0.0;                     // -L[li][jj] / L[jj][jj]
         OF_DPP_FENCE();
 #define OF_UPD(C) if (C > jj) of_fmac_bcast<C>(e[C], l, nl);            /* D[li][C] -= L[li][jj] L[C][jj] */
+#define OF_INV(K) if (jj == K) { _Pragma("unroll") for (int c = 0; c < 16; ++c) if (c <= K) of_fmac_bcast<K>(t[c], t[c], s_); }
         OF_UPD(1) OF_UPD(2) OF_UPD(3) OF_UPD(4) OF_UPD(5) OF_UPD(6) OF_UPD(7) OF_UPD(8) OF_UPD(9) OF_UPD(10) OF_UPD(11) OF_UPD(12) OF_UPD(13) OF_UPD(14) OF_UPD(15)
+        OF_INV(0) OF_INV(1) OF_INV(2) OF_INV(3) OF_INV(4) OF_INV(5) OF_INV(6) OF_INV(7) OF_INV(8) OF_INV(9) OF_INV(10) OF_INV(11) OF_INV(12) OF_INV(13) OF_INV(14)
 #undef OF_UPD
+#undef OF_INV
         OF_DPP_FENCE();
     }
     if (!ok) return false;
-    // X = L^-1 row by row: t[c] = delta(li, c) - sum_{k < li} L[li][k] X[k][c]; row k is final once scaled by 1 / L[k][k]
 #pragma unroll
-    for (int c = 0; c < 16; ++c) t[c] = (c == li) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) if (c <= k) t[c] = (li == k) ? t[c] * dinv : t[c];
-        if (k < 15) {
-            const double s_ = (li > k) ? -e[k] : 0.0;
-            OF_DPP_FENCE();
-#define OF_INV(K) if (k == K) { _Pragma("unroll") for (int c = 0; c < 16; ++c) if (c <= K) of_fmac_bcast<K>(t[c], t[c], s_); }
-            OF_INV(0) OF_INV(1) OF_INV(2) OF_INV(3) OF_INV(4) OF_INV(5) OF_INV(6) OF_INV(7) OF_INV(8) OF_INV(9) OF_INV(10) OF_INV(11) OF_INV(12) OF_INV(13) OF_INV(14)
-#undef OF_INV
-        }
-    }
+    for (int c = 0; c < 16; ++c) t[c] *= dinv;
     if (lk == 0) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            if (c <= li) G[OF_G(16 * jb + li, 16 * jb + c)] = e[c];
             T16[li * 17 + c] = (c <= li) ? t[c] : 0.0;
             Li[OF_AT(16 * jb + c, 16 * jb + li)] = (c <= li) ? t[c] : 0.0;          // L^-1[al' = row][al = col] at OF_AT(al, al')
         }

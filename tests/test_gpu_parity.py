@@ -285,29 +285,30 @@ def test_orthogonalize_full_size_vs_oracle(T, center):
 
 @pytest.mark.parametrize("d,r,center,seed", [(30, 64, 1, 0), (30, 64, 12, 1), (16, 37, 1, 2), (12, 20, 5, 3), (30, 64, 30, 4), (9, 5, 2, 5)])
 def test_orthogonalize_three_launch_form(T, monkeypatch, d, r, center, seed):
-    """The form large batches of rank <= 64 QTT trains take (csrc/ttn_ortho512.h): the 1024-thread kernel up to the first tall site of
-    the right-to-left sweep, the 512-thread Cholesky-QR kernel (two workgroups per CU) over the tall sites, the 1024-thread kernel
-    for the rest and the centre core — forced here on single trains (TTN_ORTHO512=1) and compared with the oracle: ranks / gauge
-    flags exact, tensor unchanged to 1e-12, every non-centre core orthonormal to 1e-12 (src/tt_tools.jl:511-543); plus a batch of 300
-    trains through the default dispatch (which takes this form above 256 trains)."""
+    """The form rank <= 64 QTT trains take: one wave per train over the ramp sites at the right end (csrc/ttn_ortho_ramp.h), the
+    512-thread Cholesky-QR kernel (two workgroups per CU, csrc/ttn_ortho512.h) over the tall sites and the centre core, the
+    1024-thread kernel for the left sweep and for whatever the other two refuse — and the single 1024-thread launch (TTN_ORTHO512=0),
+    both compared with the oracle: ranks / gauge flags exact, tensor unchanged to 1e-12, every non-centre core orthonormal to 1e-12
+    (src/tt_tools.jl:511-543); plus a batch of 300 trains through the default dispatch."""
     rng = np.random.default_rng(500 + seed)
     x = to_product(O.rand_tt((2,) * d, r, rng))
     ref = O.orthogonalize(to_oracle(x), i=center)
-    monkeypatch.setenv("TTN_ORTHO512", "1")
-    got = T.orthogonalize(x, i=center)
-    assert got.ttv_rks == ref.ttv_rks and got.ttv_ot == ref.ttv_ot
-    assert tt_rel_diff(to_oracle(got), to_oracle(x)) < 1e-12
-    worst = 0.0
-    for j, G in enumerate(got.ttv_vec):
-        G = np.asarray(G)
-        n, rl, rr = G.shape
-        if j < center - 1:
-            Amat = G.transpose(1, 0, 2).reshape(rl * n, rr, order="F")
-            worst = max(worst, float(np.max(np.abs(Amat.T @ Amat - np.eye(rr)))))
-        elif j > center - 1:
-            Amat = G.transpose(1, 2, 0).reshape(rl, rr * n, order="F")
-            worst = max(worst, float(np.max(np.abs(Amat @ Amat.T - np.eye(rl)))))
-    assert worst < 1e-12, worst
+    for form in ("1", "0"):                 # the multi-launch form (the default for these trains), then the single 1024-thread launch
+        monkeypatch.setenv("TTN_ORTHO512", form)
+        got = T.orthogonalize(x, i=center)
+        assert got.ttv_rks == ref.ttv_rks and got.ttv_ot == ref.ttv_ot
+        assert tt_rel_diff(to_oracle(got), to_oracle(x)) < 1e-12
+        worst = 0.0
+        for j, G in enumerate(got.ttv_vec):
+            G = np.asarray(G)
+            n, rl, rr = G.shape
+            if j < center - 1:
+                Amat = G.transpose(1, 0, 2).reshape(rl * n, rr, order="F")
+                worst = max(worst, float(np.max(np.abs(Amat.T @ Amat - np.eye(rr)))))
+            elif j > center - 1:
+                Amat = G.transpose(1, 2, 0).reshape(rl, rr * n, order="F")
+                worst = max(worst, float(np.max(np.abs(Amat @ Amat.T - np.eye(rl)))))
+        assert worst < 1e-12, (form, worst)
     monkeypatch.delenv("TTN_ORTHO512")
     if seed == 2:
         B = 300
