@@ -62,12 +62,8 @@ __device__ __forceinline__ bool o5_diag_block(int jb, lds_f64* G, lds_f64* T16, 
         const double nl = -l;
         const double s_ = (li > jj) ? nl * rs : 0.0;                       // -L[li][jj] / L[jj][jj]
         OF_DPP_FENCE();
-#define O5_UPD(C) if (C > jj) of_fmac_bcast<C>(e[C], l, nl);
-#define O5_INV(K) if (jj == K) { _Pragma("unroll") for (int c = 0; c < 16; ++c) if (c <= K) of_fmac_bcast<K>(t[c], t[c], s_); }
-        O5_UPD(1) O5_UPD(2) O5_UPD(3) O5_UPD(4) O5_UPD(5) O5_UPD(6) O5_UPD(7) O5_UPD(8) O5_UPD(9) O5_UPD(10) O5_UPD(11) O5_UPD(12) O5_UPD(13) O5_UPD(14) O5_UPD(15)
-        O5_INV(0) O5_INV(1) O5_INV(2) O5_INV(3) O5_INV(4) O5_INV(5) O5_INV(6) O5_INV(7) O5_INV(8) O5_INV(9) O5_INV(10) O5_INV(11) O5_INV(12) O5_INV(13) O5_INV(14)
-#undef O5_UPD
-#undef O5_INV
+        DPP_FACTOR_GROUP(jj, e, l, nl);          // (one asm statement per group: csrc/ttn_ortho_dpp_gen.h)
+        DPP_INVERSE_GROUP(jj, t, s_);
         OF_DPP_FENCE();
     }
     if (!ok) return false;

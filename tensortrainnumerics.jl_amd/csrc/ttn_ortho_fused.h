@@ -22,6 +22,7 @@
 //       Y_j from the accumulators;  P6  max |Q^T Q - I| by MFMA from the image;  P7  R = L^T to global memory for the next site.
 // Ten workgroup barriers per site, no global scratch.
 #pragma once
+#include "ttn_ortho_dpp_gen.h"
 #include "ttn_common.h"
 #include "ttn_dense_kernels.h"
 #include "ttn_dot_kernels.h"
@@ -84,12 +85,8 @@ __device__ __forceinline__ bool of_diag_block(int jb, lds_f64* G, lds_f64* T16, 
         const double nl = -l;
         const double s_ = (li > jj) ? nl * rs : 0.0;                     // -L[li][jj] / L[jj][jj]
         OF_DPP_FENCE();
-#define OF_UPD(C) if (C > jj) of_fmac_bcast<C>(e[C], l, nl);            /* D[li][C] -= L[li][jj] L[C][jj] */
-#define OF_INV(K) if (jj == K) { _Pragma("unroll") for (int c = 0; c < 16; ++c) if (c <= K) of_fmac_bcast<K>(t[c], t[c], s_); }
-        OF_UPD(1) OF_UPD(2) OF_UPD(3) OF_UPD(4) OF_UPD(5) OF_UPD(6) OF_UPD(7) OF_UPD(8) OF_UPD(9) OF_UPD(10) OF_UPD(11) OF_UPD(12) OF_UPD(13) OF_UPD(14) OF_UPD(15)
-        OF_INV(0) OF_INV(1) OF_INV(2) OF_INV(3) OF_INV(4) OF_INV(5) OF_INV(6) OF_INV(7) OF_INV(8) OF_INV(9) OF_INV(10) OF_INV(11) OF_INV(12) OF_INV(13) OF_INV(14)
-#undef OF_UPD
-#undef OF_INV
+        DPP_FACTOR_GROUP(jj, e, l, nl);          // (one asm statement per group: csrc/ttn_ortho_dpp_gen.h)
+        DPP_INVERSE_GROUP(jj, t, s_);
         OF_DPP_FENCE();
     }
     if (!ok) return false;
