@@ -500,7 +500,10 @@ def bench_op(args, T, D):
     for b in range(B):
         dx.upload(b, T.rand_tt(dims, r, seed=30 + b))
     core_bytes = lambda rk: 8.0 * sum(2 * rk[k] * rk[k + 1] for k in range(d))          # noqa: E731
-    bound, flops, nbytes, kernel = "hbm", 0.0, 0.0, ("k_dot_fused" if op == "dot" else "k_" + op)
+    # orthogonalize of rank <= 64 QTT trains is three kernels (csrc/ttn_ortho_ramp.h, ttn_ortho512.h, the 1024-thread k_orthogonalize for
+    # the left sweep and for trains the other two refuse): avg_launch_ms spans all of them, first launch to last (ttn_last_launch_ms)
+    kernel_names = {"dot": "k_dot_fused", "orthogonalize": "k_ortho_ramp + k_ortho512 (+ k_orthogonalize)"}
+    bound, flops, nbytes, kernel = "hbm", 0.0, 0.0, kernel_names.get(op, "k_" + op)
     if op == "apply":
         yr = [a * c for a, c in zip(A.tto_rks, xr)]
         dy = T.DeviceTT(dims, yr, batch=B)
