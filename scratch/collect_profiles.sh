@@ -115,7 +115,15 @@ for opline in sorted(glob.glob(out + "/op_*.line")):
                 rec["kernels"][kn] = k2
         rec["kernel"] = " + ".join(rec["kernels"]) or kname
         rec["avg_ns"] = sum(v["avg_ns"] for v in rec["kernels"].values())
-    rec.update(counters(out + f"/op_{op}/pmc_*/**/*counter_collection.csv", kname))
+    if op == "orthogonalize":
+        tot = {}
+        for kn in rec.get("kernels", {}):
+            for k, v in counters(out + f"/op_{op}/pmc_*/**/*counter_collection.csv", kn).items():
+                if k.endswith("_per_launch"):
+                    tot[k] = tot.get(k, 0.0) + v
+        rec.update(tot)
+    else:
+        rec.update(counters(out + f"/op_{op}/pmc_*/**/*counter_collection.csv", kname))
     json.dump(rec, open(os.path.join(dst, f"{tag}_op_{op}.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
