@@ -396,7 +396,8 @@ def add(x: TTvector, y: TTvector) -> TTvector:
     rks = [a + b for a, b in zip(x.ttv_rks, y.ttv_rks)]
     rks[0] = 1
     rks[d] = 1
-    vec = [np.zeros((x.ttv_dims[k], rks[k], rks[k + 1])) for k in range(d)]
+    dt = np.result_type(*[c.dtype for c in x.ttv_vec], *[c.dtype for c in y.ttv_vec])       # (complex trains: the TDVP drivers)
+    vec = [np.zeros((x.ttv_dims[k], rks[k], rks[k + 1]), dtype=dt) for k in range(d)]
     rx = x.ttv_rks
     vec[0][:, :, : rx[1]] = x.ttv_vec[0]
     vec[0][:, :, rx[1]: rks[1]] = y.ttv_vec[0]
@@ -472,7 +473,7 @@ def orthogonalize(x: TTvector, i: int = 1) -> TTvector:
         FL = L[:, :rnew]
     y.ttv_ot[i - 1] = 0
     Xi = x.ttv_vec[i - 1]
-    core = np.zeros((dims[i - 1], y.ttv_rks[i - 1], y.ttv_rks[i]))
+    core = np.zeros((dims[i - 1], y.ttv_rks[i - 1], y.ttv_rks[i]), dtype=np.result_type(Xi.dtype, FR.dtype, FL.dtype))
     for k in range(dims[i - 1]):
         core[k, :, :] = FR @ Xi[k, :, :] @ FL
     y.ttv_vec[i - 1] = core
@@ -1141,6 +1142,218 @@ def tdvp_update_right_env(A, M, FR):
 def tdvp_applyH2_lsr(AAC, FL, FR, M1, M2):
     """HAAC[α,s1,s2,β] := FL[α,a,α′] * AAC[α′,s1′,s2′,β′] * M1[a,s1,b,s1′] * M2[b,s2,c,s2′] * FR[β′,c,β]  (tdvp.jl:205-208)"""
     return np.einsum("xay,ytuq,asbt,bvcu,qcz->xsvz", FL, AAC, M1, M2, FR, optimize=True)
+
+
+# --------------------------------------------------------------------------------------
+# TDVP drivers — src/solvers/tdvp.jl:45-203 (tdvp1sweep!, tdvp), :210-357 (tdvp2sweep!, tdvp2)
+#
+# `exponentiate` is KrylovKit's (Project.toml compat "0.6.1, 0.9, 0.10"; the package is not in /root/reference): for a Hermitian
+# operator its Lanczos variant builds an orthonormal Krylov basis V_m (krylovdim 30, full reorthogonalisation), exponentiates the
+# tridiagonal projection, accepts when the a-posteriori estimate beta_m |e_m^T exp(t T_m) e_1| is below tol (1e-12) and otherwise
+# advances by a shorter time and restarts (maxiter 100).  Restated here from that published algorithm; the reference's own tests
+# (test/test_tdvp.jl) pin the drivers through known answers (H = 0 -> identity, an eigenmode of the heat operator to 1e-8, A = I/2
+# -> zero residual), see tests/test_oracle_reference_pins.py.
+# --------------------------------------------------------------------------------------
+def tdvp_exponentiate(Hfun, t, x0, krylovdim: int = 30, tol: float = 1.0e-12, maxiter: int = 100):
+    """y = exp(t H) x0 for Hermitian H given as a function on arrays of x0's shape; t real or complex."""
+    shape = x0.shape
+    x = np.reshape(x0, -1, order="F").astype(np.result_type(x0.dtype, type(t), np.float64))
+    remaining = t
+    total = abs(t)
+    for _ in range(maxiter):
+        nrm = np.linalg.norm(x)
+        if nrm == 0.0 or remaining == 0:
+            break
+        n = x.size
+        m_max = min(krylovdim, n)
+        V = np.zeros((n, m_max), dtype=x.dtype if np.iscomplexobj(x) else np.result_type(x.dtype, Hfun(np.reshape(x, shape, order="F")).dtype))
+        x = x.astype(V.dtype)
+        V[:, 0] = x / nrm
+        alphas, betas = [], []
+        m = 0
+        happy = False
+        for j in range(m_max):
+            w = np.reshape(Hfun(np.reshape(V[:, j], shape, order="F")), -1, order="F").astype(V.dtype)
+            a = np.real(np.vdot(V[:, j], w))
+            alphas.append(float(a))
+            w = w - a * V[:, j]
+            if j > 0:
+                w = w - betas[j - 1] * V[:, j - 1]
+            for _r in range(2):                                             # full reorthogonalisation, twice
+                w = w - V[:, : j + 1] @ (V[:, : j + 1].conj().T @ w)
+            b = float(np.linalg.norm(w))
+            m = j + 1
+            if b <= 1.0e-14 * max(1.0, abs(a)) or m == n:
+                happy = True
+                break
+            betas.append(b)
+            if j + 1 < m_max:
+                V[:, j + 1] = w / b
+        Tm = np.diag(alphas[:m]) + np.diag(betas[: m - 1], 1) + np.diag(betas[: m - 1], -1)
+        lam, U = np.linalg.eigh(Tm)
+        tau = remaining
+        while True:
+            y = U @ (np.exp(tau * lam) * U[0, :])
+            err = 0.0 if happy else betas[m - 1] * abs(y[m - 1]) * nrm if len(betas) >= m else 0.0
+            if happy or err <= tol * max(abs(tau) / total, 1.0e-3) or abs(tau) <= 1.0e-12 * total:
+                break
+            tau = tau / 2
+        x = nrm * (V[:, :m] @ y)
+        remaining = remaining - tau
+        if abs(remaining) <= 1.0e-14 * total:
+            break
+    return np.reshape(x, shape, order="F")
+
+
+def _tdvp_real_or_complex_t(z):
+    """_real_or_complex_t: a complex number without imaginary part becomes real  (tdvp.jl:22)"""
+    z = complex(z)
+    return z.real if z.imag == 0.0 else z
+
+
+def _tdvp_envs(A_lsr, M_asbs, Tc):
+    """F[0] = F[N+1] = ones(1,1,1); F[k+1] = _update_right_env(A[k], M[k], F[k+2]) for k = N..1  (tdvp.jl:55-62)"""
+    N = len(A_lsr)
+    F = [None] * (N + 2)
+    F[0] = np.ones((1, 1, 1), dtype=Tc)
+    F[N + 1] = np.ones((1, 1, 1), dtype=Tc)
+    for k in range(N - 1, -1, -1):
+        F[k + 1] = tdvp_update_right_env(A_lsr[k], M_asbs[k], F[k + 2])
+    return F
+
+
+def _tdvp_sync(psi: TTvector, A_lsr) -> TTvector:
+    """cores back to (s, l, r), ranks from the arrays, ttv_ot zeroed  (_sync_ranks_from_lsr!, tdvp.jl:8-18, :147-151)"""
+    N = psi.N
+    psi.ttv_vec = [np.transpose(A_lsr[k], (1, 0, 2)).copy() for k in range(N)]
+    psi.ttv_rks = [A_lsr[k].shape[0] for k in range(N)] + [A_lsr[N - 1].shape[2]]
+    psi.ttv_ot = [0] * N
+    return psi
+
+
+def tdvp1sweep_(dt, psi: TTvector, H: TToperator, F=None, **kw):
+    """tdvp1sweep! (tdvp.jl:45-152): one left-to-right and one right-to-left pass of one-site TDVP.  Mutates and returns (psi, F)."""
+    Tc = np.complex128 if (isinstance(dt, complex) or np.iscomplexobj(psi.ttv_vec[0])) else np.float64
+    N = psi.N
+    A = [np.transpose(psi.ttv_vec[k], (1, 0, 2)) for k in range(N)]
+    M = [np.transpose(H.tto_vec[k], (2, 0, 3, 1)) for k in range(N)]
+    F = _tdvp_envs(A, M, Tc) if F is None else [np.asarray(f, dtype=Tc) for f in F]
+    AC = A[0].astype(Tc)
+    tm = _tdvp_real_or_complex_t(-1j * complex(dt))
+    tp = _tdvp_real_or_complex_t(+1j * complex(dt))
+    for k in range(N - 1):
+        AC = tdvp_exponentiate(lambda x: tdvp_applyH1_lsr(x, F[k], F[k + 2], M[k]), tm, AC, **kw)
+        Dl, d, Dr = AC.shape
+        Q, R = sla.qr(np.reshape(AC, (Dl * d, Dr), order="F"), mode="economic")
+        r = min(Dl * d, Dr)
+        AL = np.reshape(Q[:, :r], (Dl, d, r), order="F")
+        A[k] = AL
+        F[k + 1] = tdvp_update_left_env(AL, M[k], F[k])
+        C = tdvp_exponentiate(lambda x: tdvp_applyH0(x, F[k + 1], F[k + 2]), tp, R[:r, :], **kw)
+        AC = np.einsum("ag,gsb->asb", C, A[k + 1])
+    k = N - 1
+    AC = tdvp_exponentiate(lambda x: tdvp_applyH1_lsr(x, F[k], F[k + 2], M[k]), tm, AC, **kw)
+    for k in range(N - 2, -1, -1):
+        Dl, d, Dr = AC.shape
+        Amat = np.reshape(AC, (Dl, d * Dr), order="F")
+        Q, R = sla.qr(Amat.conj().T, mode="economic")
+        r = min(Dl, d * Dr)
+        L = R[:r, :].conj().T
+        A_r = np.reshape(Q[:, :r].conj().T, (r, d, Dr), order="F")
+        A[k + 1] = A_r
+        F[k + 2] = tdvp_update_right_env(A_r, M[k + 1], F[k + 3])
+        C = tdvp_exponentiate(lambda x: tdvp_applyH0(x, F[k + 1], F[k + 2]), tp, L, **kw)
+        AC = np.einsum("asg,gb->asb", A[k], C)
+        AC = tdvp_exponentiate(lambda x: tdvp_applyH1_lsr(x, F[k], F[k + 2], M[k]), tm, AC, **kw)
+    A[0] = AC
+    return _tdvp_sync(psi, A), F
+
+
+def tdvp2sweep_(dt, psi: TTvector, H: TToperator, F=None, max_bond: int = 2 ** 62, truncerr: float = 0.0, **kw):
+    """tdvp2sweep! (tdvp.jl:210-301): two-site TDVP with SVD truncation, half steps forward on the pairs, back on the sites."""
+    Tc = np.complex128 if (isinstance(dt, complex) or np.iscomplexobj(psi.ttv_vec[0])) else np.float64
+    N = psi.N
+    dth = complex(dt) / 2
+    A = [np.transpose(psi.ttv_vec[k], (1, 0, 2)) for k in range(N)]
+    M = [np.transpose(H.tto_vec[k], (2, 0, 3, 1)) for k in range(N)]
+    F = _tdvp_envs(A, M, Tc) if F is None else [np.asarray(f, dtype=Tc) for f in F]
+    AC = A[0].astype(Tc)
+    tm = _tdvp_real_or_complex_t(-1j * dth)
+    tp = _tdvp_real_or_complex_t(+1j * dth)
+    for k in range(N - 1):
+        AAC = np.einsum("asg,gtb->astb", AC, A[k + 1])
+        AAC = tdvp_exponentiate(lambda x: tdvp_applyH2_lsr(x, F[k], F[k + 3], M[k], M[k + 1]), tm, AAC, **kw)
+        Dl, d1, d2, Dr = AAC.shape
+        U, s, Vt = svdtrunc(np.reshape(AAC, (Dl * d1, d2 * Dr), order="F"), max_bond=max_bond, truncerr=truncerr)
+        AL = np.reshape(U, (Dl, d1, U.shape[1]), order="F")
+        A[k] = AL
+        F[k + 1] = tdvp_update_left_env(AL, M[k], F[k])
+        AC = np.reshape(s[:, None] * Vt, (len(s), d2, Dr), order="F")
+        if k < N - 2:
+            AC = tdvp_exponentiate(lambda x: tdvp_applyH1_lsr(x, F[k + 1], F[k + 3], M[k + 1]), tp, AC, **kw)
+    for k in range(N - 2, -1, -1):
+        AAC = np.einsum("asg,gtb->astb", A[k], AC)
+        AAC = tdvp_exponentiate(lambda x: tdvp_applyH2_lsr(x, F[k], F[k + 3], M[k], M[k + 1]), tm, AAC, **kw)
+        Dl, d1, d2, Dr = AAC.shape
+        U, s, Vt = svdtrunc(np.reshape(AAC, (Dl * d1, d2 * Dr), order="F"), max_bond=max_bond, truncerr=truncerr)
+        AR = np.reshape(Vt, (Vt.shape[0], d2, Dr), order="F")
+        A[k + 1] = AR
+        F[k + 2] = tdvp_update_right_env(AR, M[k + 1], F[k + 3])
+        AC = np.reshape(U * s[None, :], (Dl, d1, len(s)), order="F")
+        if k > 0:
+            AC = tdvp_exponentiate(lambda x: tdvp_applyH1_lsr(x, F[k], F[k + 2], M[k]), tp, AC, **kw)
+    A[0] = AC
+    return _tdvp_sync(psi, A), F
+
+
+def _tdvp_complex(x: TTvector) -> TTvector:
+    return TTvector(x.N, [c.astype(np.complex128) for c in x.ttv_vec], tuple(x.ttv_dims), list(x.ttv_rks), list(x.ttv_ot))
+
+
+def _tdvp_complex_op(H: TToperator) -> TToperator:
+    return TToperator(H.N, [c.astype(np.complex128) for c in H.tto_vec], tuple(H.tto_dims), list(H.tto_rks), list(H.tto_ot))
+
+
+def _tdvp_driver(sweep, H: TToperator, u0: TTvector, steps, normalize=True, return_error=False, sweeps=1, carry_env=True,
+                 imaginary_time=False, **kw):
+    """tdvp / tdvp2 (tdvp.jl:154-203, :303-357).  A real train stays real in imaginary time (the reference stores the complex local
+    arrays back into a real TTvector: their imaginary parts are zero)."""
+    psi = orthogonalize(u0)
+    real_out = imaginary_time and not np.iscomplexobj(u0.ttv_vec[0])
+    if not imaginary_time:
+        psi = _tdvp_complex(psi)
+    Hc = _tdvp_complex_op(H) if (not imaginary_time and not np.iscomplexobj(H.tto_vec[0])) else H
+    psi_prev = psi
+    F = None
+    for h in steps:
+        psi_prev_step = copy_tt(psi)
+        dt_eff = (1j * h) if imaginary_time else complex(h)
+        for _ in range(sweeps):
+            psi, F = sweep(dt_eff, psi, Hc, F if carry_env else None, **kw)
+            if real_out:
+                assert max(float(np.max(np.abs(np.imag(c)))) for c in psi.ttv_vec) <= 1e-12 * max(1.0, max(float(np.max(np.abs(c))) for c in psi.ttv_vec))
+                psi.ttv_vec = [np.real(c).copy() for c in psi.ttv_vec]
+        if normalize:
+            psi = scale(1 / norm(psi), psi)
+        psi = orthogonalize(psi)
+        F = None
+        psi_prev = psi_prev_step
+    if return_error:
+        h = steps[-1]
+        if imaginary_time:
+            residual = sub(scale(1 / h, sub(psi, psi_prev)), apply(Hc, psi))
+        else:
+            residual = add(scale(1 / h, sub(psi, psi_prev)), scale(1j, apply(Hc, psi)))
+        return psi, norm(residual) / norm(psi)
+    return psi
+
+
+def tdvp(H, u0, steps, **kw):
+    return _tdvp_driver(tdvp1sweep_, H, u0, steps, **kw)
+
+
+def tdvp2(H, u0, steps, max_bond: int = 2 ** 62, truncerr: float = 0.0, **kw):
+    return _tdvp_driver(lambda dt, psi, Hc, F, **k2: tdvp2sweep_(dt, psi, Hc, F, max_bond=max_bond, truncerr=truncerr, **k2), H, u0, steps, **kw)
 
 
 # --------------------------------------------------------------------------------------

@@ -546,3 +546,116 @@ def test_tdvp_applyH2_equals_two_site_loop():
                                               for ai in range(a) for ap in range(Dl) for t1 in range(d1) for t2 in range(d2)
                                               for bp in range(Dr) for bi in range(b) for ci in range(c))
     assert np.allclose(O.tdvp_applyH2_lsr(AAC, FL, FR, M1, M2), ref, rtol=1e-12, atol=1e-12)
+
+
+# --------------------------------------------------------------------------------------
+# TDVP drivers (test/test_tdvp.jl:147-375): the reference's known answers, restated on the oracle's tdvp1sweep_ / tdvp2sweep_ / tdvp / tdvp2
+# --------------------------------------------------------------------------------------
+def _absnorm(x):
+    return math.sqrt(max(float(np.real(O.dot(x, x))), 0.0))
+
+
+def _tt_rel(a, b):
+    """The reference measures absnorm(a - b) / absnorm(b) through the TT dot product of the difference train; that number is
+    sqrt(rounding of ||a||^2 - 2 <a, b> + ||b||^2) ~ 1e-8 ||a|| whenever it does not round to exactly zero, so its bars (1e-12, 1e-10)
+    are restated on the dense tensors (d <= 6 here), where they mean what they say."""
+    ta, tb = O.ttv_to_tensor(a), O.ttv_to_tensor(b)
+    return float(np.linalg.norm(ta - tb) / max(np.linalg.norm(tb), np.finfo(float).eps))
+
+
+def _zero_id(d, cplx):
+    H = O.tto_scale(0.0, O.id_tto(d))
+    return O._tdvp_complex_op(H) if cplx else H
+
+
+def test_tdvp1sweep_zero_hamiltonian_is_the_identity():
+    d = 4                                                               # test/test_tdvp.jl:147-160
+    psi = O._tdvp_complex(O.orthogonalize(O.qtt_sin(d, lam=math.pi)))
+    psi2, F = O.tdvp1sweep_(complex(0.1), O.copy_tt(psi), _zero_id(d, True), None)
+    assert _tt_rel(psi2, psi) < 1e-12
+    assert len(F) == psi.N + 2
+
+
+def test_tdvp_basic_behaviour():
+    d = 4                                                               # test/test_tdvp.jl:164-206
+    u0 = O.qtt_sin(d, lam=math.pi)
+    kw = dict(normalize=False, sweeps=1, carry_env=False)
+    psi_rt = O.tdvp(_zero_id(d, True), O._tdvp_complex(u0), [0.1], imaginary_time=False, **kw)
+    assert np.iscomplexobj(psi_rt.ttv_vec[0])
+    psi_it = O.tdvp(_zero_id(d, False), u0, [0.1], imaginary_time=True, **kw)
+    assert not np.iscomplexobj(psi_it.ttv_vec[0])
+    _, err = O.tdvp(_zero_id(d, True), O._tdvp_complex(u0), [0.1], imaginary_time=False, return_error=True, **kw)
+    assert abs(err) <= 1e-6
+    psi0 = O._tdvp_complex(O.orthogonalize(u0))
+    psi_id = O.tdvp(_zero_id(d, True), psi0, [0.1], imaginary_time=False, **kw)
+    assert _tt_rel(psi_id, psi0) <= 1e-10
+    a = O.tdvp(_zero_id(d, True), O._tdvp_complex(u0), [0.1, 0.1], normalize=False, sweeps=2, carry_env=True, imaginary_time=False)
+    b = O.tdvp(_zero_id(d, True), O._tdvp_complex(u0), [0.1, 0.1], normalize=False, sweeps=2, carry_env=False, imaginary_time=False)
+    assert _tt_rel(a, b) <= 1e-10
+
+
+def test_tdvp2sweep_zero_hamiltonian_and_max_bond():
+    d = 4                                                               # test/test_tdvp.jl:236-268
+    psi0 = O._tdvp_complex(O.orthogonalize(O.qtt_sin(d, lam=math.pi)))
+    for dt in (0.1j, 0.05, 0.05j):
+        psi1, F1 = O.tdvp2sweep_(dt, O.copy_tt(psi0), _zero_id(d, True), None)
+        assert len(F1) == psi0.N + 2 and F1[0].shape == (1, 1, 1) and F1[-1].shape == (1, 1, 1)
+        assert np.allclose(O.ttv_to_tensor(psi1), O.ttv_to_tensor(psi0), atol=1e-10, rtol=1e-10)
+    d = 6
+    psi0 = O._tdvp_complex(O.orthogonalize(O.add(O.qtt_sin(d, lam=math.pi), O.qtt_sin(d, lam=2 * math.pi))))
+    psi2, _ = O.tdvp2sweep_(0.1j, O.copy_tt(psi0), _zero_id(d, True), None, max_bond=2, truncerr=0.0)
+    assert max(psi2.ttv_rks) <= 2
+
+
+def test_tdvp2_basic_behaviour():
+    d = 6                                                               # test/test_tdvp.jl:270-317
+    u0 = O.qtt_sin(d, lam=math.pi)
+    kw = dict(normalize=False, sweeps=1, carry_env=False)
+    assert np.iscomplexobj(O.tdvp2(_zero_id(d, True), O._tdvp_complex(u0), [0.1], imaginary_time=False, **kw).ttv_vec[0])
+    assert not np.iscomplexobj(O.tdvp2(_zero_id(d, False), u0, [0.1], imaginary_time=True, **kw).ttv_vec[0])
+    _, err = O.tdvp2(_zero_id(d, True), O._tdvp_complex(u0), [0.1], imaginary_time=False, return_error=True, **kw)
+    assert abs(err) <= 1e-6
+    psi0 = O._tdvp_complex(O.orthogonalize(u0))
+    assert _tt_rel(O.tdvp2(_zero_id(d, True), psi0, [0.1], imaginary_time=False, **kw), psi0) <= 1e-7
+    a = O.tdvp2(_zero_id(d, True), O._tdvp_complex(u0), [0.1, 0.1], normalize=False, sweeps=2, carry_env=True, imaginary_time=False)
+    b = O.tdvp2(_zero_id(d, True), O._tdvp_complex(u0), [0.1, 0.1], normalize=False, sweeps=2, carry_env=False, imaginary_time=False)
+    assert _tt_rel(a, b) <= 1e-10
+    d = 4                                                               # test/test_tdvp.jl:319-327: the imaginary-time branch on a complex train
+    psi0 = O._tdvp_complex(O.orthogonalize(O.qtt_sin(d, lam=math.pi)))
+    psi_it = O.tdvp2(_zero_id(d, True), psi0, [0.02, 0.02], normalize=False, sweeps=2, carry_env=True, imaginary_time=True)
+    assert _tt_rel(psi_it, psi0) < 1e-12
+
+
+def heat_problem(d=4, kappa=0.1):
+    """test/test_tdvp.jl:329-356: A = (kappa / h^2) (Delta ⊗ I + I ⊗ Delta) on 2 d bits in serial order, u0 = sin ⊗ sin on the
+    interior grid, an eigenvector of A: exp(lambda t) u0 is the exact solution."""
+    N = 2 ** d
+    h = 1.0 / (N + 1)
+    D1, I1 = O.toeplitz_to_qtto(-2.0, 1.0, 1.0, d), O.id_tto(d)
+    kron = lambda X, Y: O.TToperator(2 * d, [c.copy() for c in X.tto_vec] + [c.copy() for c in Y.tto_vec], tuple(X.tto_dims) + tuple(Y.tto_dims),     # noqa: E731
+                                     list(X.tto_rks) + list(Y.tto_rks[1:]), [0] * (2 * d))
+    A = O.tto_scale(kappa / h ** 2, O.tto_add(kron(D1, I1), kron(I1, D1)))
+    s1 = O.qtt_sin(d, a=h, b=1 - h)
+    u0 = O.TTvector(2 * d, [c.copy() for c in s1.ttv_vec] * 2, tuple(s1.ttv_dims) * 2, list(s1.ttv_rks) + list(s1.ttv_rks[1:]), [0] * (2 * d))
+    lam = float(np.real(O.dot(u0, O.apply(A, u0)) / O.dot(u0, u0)))
+    return A, u0, lam
+
+
+def test_tdvp_heat_eigenmode():
+    A, u0, lam = heat_problem()
+    steps = [1e-3] * 5
+    target = math.exp(lam * sum(steps)) * O.ttv_to_tensor(u0)
+    sol = O.tdvp(A, u0, steps, imaginary_time=True, normalize=False)
+    assert np.linalg.norm(O.ttv_to_tensor(sol) - target) / np.linalg.norm(target) < 1e-8
+    sol2 = O.tdvp2(A, u0, steps, imaginary_time=True, normalize=False, max_bond=8, truncerr=1e-12)
+    assert np.linalg.norm(O.ttv_to_tensor(sol2) - target) / np.linalg.norm(target) < 1e-8
+
+
+def test_tdvp_return_error_residual_both_time_directions():
+    d = 4                                                               # test/test_tdvp.jl:358-375: A = I/2 -> every state evolves exactly
+    A = O.tto_scale(0.5, O.id_tto(d))
+    u0 = O.qtt_sin(d, lam=math.pi)
+    for it in (False, True):
+        _, e1 = O.tdvp(A, u0, [1e-3] * 5, imaginary_time=it, return_error=True, normalize=False)
+        _, e2 = O.tdvp2(A, u0, [1e-3] * 5, imaginary_time=it, return_error=True, normalize=False, max_bond=8, truncerr=1e-12)
+        assert e1 < 1e-3 and e2 < 1e-3
