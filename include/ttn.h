@@ -276,6 +276,10 @@ int ttn_prof_get(int64_t b, int64_t* out8);
 /* per bond step (first 120 steps): (p << 32) | jacobi_sweeps, p = short side of the merged matrix */
 int ttn_prof_steps(int64_t b, int64_t* out120);
 int ttn_prof_fine(int64_t b, int64_t* out64);       /* TTN_PROF_STEP=k: 64 fine-grained cycle counters of bond step k of train b */
+/* diagnostics of the last ttn_orthogonalize that took the multi-launch form (csrc/ttn_ortho_ramp.h, ttn_ortho512.h): the four state
+ * words of train b = {next site of the right-to-left sweep, buffer of the last right factor, buffer of the last left factor,
+ * 1 if k_ortho512 finished the train (0: the 1024-thread kernel took it over from `next site`)}. */
+int ttn_debug_ortho_state(int64_t b, int64_t* out4);
 
 /* ---- stateless host-pointer entry points: the literal drop-ins for one train --------------------
  * Each uploads, runs the handle op above, and downloads.  Output cores are caller-allocated:

@@ -70,6 +70,7 @@ SIGNATURES = {
     "ttn_dot": (C.c_int, [handle, handle, p_f64]),
     "ttn_norm": (C.c_int, [handle, p_f64]),
     "ttn_last_launch_ms": (C.c_int, [C.POINTER(C.c_float)]),
+    "ttn_debug_ortho_state": (C.c_int, [i64, p_i64]),
     "ttn_hadamard": (C.c_int, [handle, handle, handle]),
     "ttn_hadamard_ttm": (C.c_int, [handle, handle, handle, C.c_double, i64, i64]),
     "ttn_swap_sites": (C.c_int, [handle, i64, p_i64, C.c_double]),

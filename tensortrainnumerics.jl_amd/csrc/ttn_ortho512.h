@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(O5_WG, 4) k_ortho512(OrthoArgs P) {
     bool first = true;
     double* Xbase = X.data + (long long)b * X.stride;
     double* Ybase = Y.data + (long long)b * Y.stride;
-    while (j > ic) {
+    while (j > ic && !(P.no_cholqr & 2)) {                                  // (TTN_ORTHO_CHOLQR = 0 / 1: no Cholesky-QR steps — everything is handed to the general route)
         const int rl = uni32(tab[4 * j]), rr = uni32(tab[4 * j + 4]), n = uni32(tab[4 * j + 1]);
         const int ynext = uni32((int)yr[j + 1]);
         if (!ortho512_eligible(n, rl, rr, ynext)) break;
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(O5_WG, 4) k_ortho512(OrthoArgs P) {
     }
     __syncthreads();
     int done = 0;
-    if (j == ic) {
+    if (j == ic && !(P.no_cholqr & 2)) {
         // ---- the centre core Y_i[s] = FR X_i[s] FL (src/tt_tools.jl:537-541) here as well: a third launch of 1024-thread workgroups
         //      for two small products costs 4 ms of workgroup dispatch on a batch of 1024 (measured) ----
         const int n = uni32(tab[4 * ic + 1]), rl = uni32(tab[4 * ic]), rr = uni32(tab[4 * ic + 4]);

@@ -324,6 +324,65 @@ def test_orthogonalize_three_launch_form(T, monkeypatch, d, r, center, seed):
             assert yb.ttv_rks == O.orthogonalize(to_oracle(xs[b % 4]), i=center).ttv_rks
 
 
+def _ortho_checks(O_, got, x, center, tol=1e-12):
+    ref = O_.orthogonalize(to_oracle(x), i=center)
+    assert got.ttv_rks == ref.ttv_rks and got.ttv_ot == ref.ttv_ot
+    assert tt_rel_diff(to_oracle(got), to_oracle(x)) < tol
+    worst = 0.0
+    for j, G in enumerate(got.ttv_vec):
+        G = np.asarray(G)
+        n, rl, rr = G.shape
+        if j < center - 1:
+            Amat = G.transpose(1, 0, 2).reshape(rl * n, rr, order="F")
+            worst = max(worst, float(np.max(np.abs(Amat.T @ Amat - np.eye(rr)))))
+        elif j > center - 1:
+            Amat = G.transpose(1, 2, 0).reshape(rl, rr * n, order="F")
+            worst = max(worst, float(np.max(np.abs(Amat @ Amat.T - np.eye(rl)))))
+    assert worst < tol, worst
+
+
+def test_orthogonalize_hand_over_between_the_kernels(T, monkeypatch):
+    """The rarely taken paths of the multi-launch form: (a) the 512-thread kernel takes nothing (TTN_ORTHO_CHOLQR=1 forbids its
+    Cholesky-QR steps): the 1024-thread kernel resumes every train right behind the ramp kernel, from the compacted list; (b) a train
+    whose tall sites are numerically rank deficient (pairs of columns equal to 1e-9: cond ~ 1e9, a Cholesky pivot fails or the measured
+    orthogonality is far above the bar): the step is REFUSED in the middle of the sweep and the general route (Householder) finishes
+    that train, while its neighbours in the batch finish in the 512-thread kernel.  Same checks as everywhere: ranks / gauge flags
+    exact, tensor unchanged, every non-centre core orthonormal to 1e-12 (src/tt_tools.jl:511-543)."""
+    rng = np.random.default_rng(77)
+    d, r = 14, 24
+    x = to_product(O.rand_tt((2,) * d, r, rng))
+    monkeypatch.setenv("TTN_ORTHO512", "1")
+    monkeypatch.setenv("TTN_ORTHO_CHOLQR", "1")
+    for center in (1, 6):
+        _ortho_checks(O, T.orthogonalize(x, i=center), x, center)
+    monkeypatch.delenv("TTN_ORTHO_CHOLQR")
+    # (b) ill-conditioned tall sites: column al' of core 7 and 8 nearly equal to column al' - 1
+    bad = to_oracle(x)
+    for k in (6, 7):
+        c = bad.ttv_vec[k]
+        c[:, 1::2, :] = c[:, 0::2, :][:, : c[:, 1::2, :].shape[1], :] + 1e-9 * c[:, 1::2, :]
+    bad = to_product(bad)
+    B = 20
+    good = [to_product(O.rand_tt((2,) * d, r, rng)) for _ in range(3)]
+    dx = T.DeviceTT((2,) * d, x.ttv_rks, batch=B)
+    for b in range(B):
+        dx.upload(b, bad if b in (3, 11) else good[b % 3])
+    dy = T.DeviceTT((2,) * d, x.ttv_rks, batch=B)
+    T.device.orthogonalize(dx, 1, dy)
+    # the state words of the launch (diagnostic hook of the library): [next site, right buffer, left buffer, finished by k_ortho512]
+    import ctypes as C
+    finished = []
+    for b in range(B):
+        st = (C.c_int64 * 4)()
+        T._lib.check(T._lib.lib().ttn_debug_ortho_state(b, st))
+        finished.append(int(st[3]))
+    assert [b for b in range(B) if not finished[b]] == [3, 11], finished        # refused exactly where the sites are rank deficient
+    for b in (0, 3, 4, 11, 19):
+        src = bad if b in (3, 11) else good[b % 3]
+        _ortho_checks(O, dy.download(b), src, 1, tol=1e-11 if b in (3, 11) else 1e-12)
+    monkeypatch.delenv("TTN_ORTHO512")
+
+
 # ------------------------------------------------------------------------------------------------
 # _tt_bond_truncate! / tt_compress!
 # ------------------------------------------------------------------------------------------------

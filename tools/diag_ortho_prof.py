@@ -39,8 +39,6 @@ for b in sorted({0, B - 1}):
 if os.environ.get("TTN_ORTHO512") == "1":
     import ctypes as C2
     fn = T._lib.lib().ttn_debug_ortho_state
-    fn.restype = C2.c_int
-    fn.argtypes = [C2.c_int64, C2.POINTER(C2.c_int64)]
     for b in sorted({0, B - 1}):
         o = (C2.c_int64 * 4)()
         fn(b, o)
