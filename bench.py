@@ -485,7 +485,7 @@ def bench_core_sharded(args, T, D, torch, dist, rank, world, red_device):
 # ------------------------------------------------------------------------------------------------------------------
 # --op: roofline lines of the other hot-path kernels
 # ------------------------------------------------------------------------------------------------------------------
-def bench_op(args, T, D):
+def bench_op(args, T, D, emit=True):
     """One C3-shaped batch, one kernel: bytes (or flops) / HIP-event time / peak.  Algorithmic bytes = the cores read + the cores
     written, once each; algorithmic flops of dot = sum_k 2 n (rA rB rB' + rA rA' rB'), of orthogonalize = the
     Householder QR/LQ count 2 m n^2 - 2/3 n^3 per core plus forming Q (the same again) plus the R / L carry GEMM."""
@@ -581,7 +581,9 @@ def bench_op(args, T, D):
                         "frac": round(achieved / peak, 4), "traffic": None, "algorithmic_bytes_per_launch": nbytes,
                         "algorithmic_flops_per_launch": flops, "avg_launch_ms": round(t * 1e3, 4),
                         "call_ms_incl_host_sync": round(call_ms, 4)}}
-    print(json.dumps(res), flush=True)
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
 
 
 def main():
@@ -596,6 +598,7 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the batch sweep B = 1, 8, 64, 256")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run check of downloaded trains against the oracle")
     ap.add_argument("--no-c2", action="store_true", help="skip the C2 (d=20, rank 32) sub-record")
+    ap.add_argument("--no-ops", action="store_true", help="skip the other_kernels sub-record (apply / add / scale / hadamard / dot / orthogonalize)")
     ap.add_argument("--no-core-sharded", action="store_true", help="N>1: skip the core-wise sharded (C4) sub-record")
     ap.add_argument("--core-sharded-timeout", type=int, default=240, help="N>1: watchdog of the C4 sub-record in seconds")
     ap.add_argument("--shard", default="trains", choices=["trains", "cores"],
@@ -677,6 +680,21 @@ def main():
         extras["batch_sweep"] = batch_sweep(T, D, d, r)
         extras["single_train"] = extras["batch_sweep"][0]
         extras["drop_in"] = drop_in_latency(T, d, r)
+    # ---- the other hot-path kernels as driver-observed sub-records: the same measurement as `--op X`, on a batch of
+    #      256 (streaming kernels: 3 GB of output per launch at most) or 1024 (dot / orthogonalize) C3-shaped trains; < 3 s in all ----
+    if rank == 0 and world == 1 and not args.no_ops and (d, r) == (30, 64):
+        import copy
+        ops = {}
+        for op, ob in (("apply", 256), ("add", 256), ("scale", 256), ("hadamard", 256), ("dot", 1024), ("orthogonalize", 1024)):
+            a2 = copy.copy(args)
+            a2.op, a2.batch, a2.steps, a2.warmup = op, ob, 5, 2
+            try:
+                rec = bench_op(a2, T, D, emit=False)
+                ops[op] = {"batch": ob, "ms_per_launch": rec["ms_per_step"], "bound": rec["roofline"]["bound"], "achieved": rec["roofline"]["achieved"],
+                           "unit": rec["roofline"]["unit"], "frac": rec["roofline"]["frac"], "kernel": rec["roofline"]["kernel"]}
+            except Exception as e:                                   # a sub-record must never cost the headline line
+                ops[op] = {"error": repr(e)[:200]}
+        extras["other_kernels"] = ops
     # ---- BASELINE config C2 (d = 20, rank 32) as a driver-observed sub-record, same op, same batch size (12 ms per step) ----
     c2 = None
     if not args.no_c2 and (d, r) == (30, 64):

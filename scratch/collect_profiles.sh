@@ -11,7 +11,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-single --no-verify --no-c2"
+CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-single --no-verify --no-c2 --no-ops"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $CMD > $OUT/line.json 2> $OUT/stats.err
 for C in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F64"; do
   N=$(echo $C | tr ' ' '_')
@@ -88,7 +88,7 @@ if "FETCH_SIZE_per_launch" in kc and "WRITE_SIZE_per_launch" in kc:
     w, f = kc["WRITE_SIZE_per_launch"] * 1024.0, kc["FETCH_SIZE_per_launch"] * 1024.0
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     json.dump({"kernel": "k_compress", "tag": tag, "commit": commit or None, "d": cfg.get("d"), "rank": cfg.get("rank"), "batch": cfg.get("batch_per_gpu"),
-               "command": "bench.py --steps 3 --warmup 1 --no-cpu --no-single --no-verify --no-c2 under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
+               "command": "bench.py --steps 3 --warmup 1 --no-cpu --no-single --no-verify --no-c2 --no-ops under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
                "write_bytes_per_launch": w, "fetch_bytes_per_launch_raw": f,
                "traffic_bytes_per_launch": w + f, "traffic_bytes_per_launch_upper": w + 2 * f,
                "note": "raw FETCH_SIZE under-counts wide coalesced reads by 1/2 on gfx950 and is uncalibrated for 8-byte strided reads: "
