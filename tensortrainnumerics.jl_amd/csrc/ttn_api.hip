@@ -580,7 +580,9 @@ int ttn_hadamard(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z) {
     for (int k = 0; k < d; ++k) maxpq = std::max<long long>(maxpq, (long long)x->bound[k] * y->bound[k] * x->bound[k + 1] * y->bound[k + 1]);
     if (stream_fibres_too_many(maxpq)) return fail(TTN_ERR_UNSUPPORTED, "ttn_hadamard: 2^31 or more fibres in one core (32-bit element indices)");
     hipLaunchKernelGGL(k_ranks_mul, dim3(x->batch), dim3(64), 0, g_stream, z->dev(), x->dev(), y->dev());
-    hipLaunchKernelGGL(k_hadamard, stream_grid(maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), z->dev());
+    bool qtt = true;
+    for (int k = 0; k < d; ++k) qtt = qtt && x->dims[k] == 2;
+    hipLaunchKernelGGL(k_hadamard, stream_grid(qtt ? (maxpq + TTN_HAD_K - 1) / TTN_HAD_K : maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), z->dev());
     HIPCHK(hipGetLastError());
     for (int m = 0; m <= d; ++m) z->bound[m] = x->bound[m] * y->bound[m];
     std::fill(z->ot.begin(), z->ot.end(), 0);
@@ -603,7 +605,9 @@ int ttn_add(ttn_tt_t x, ttn_tt_t y, ttn_tt_t z) {
     for (int k = 0; k < d; ++k) maxpq = std::max<long long>(maxpq, (long long)zb[k] * zb[k + 1]);
     if (stream_fibres_too_many(maxpq)) return fail(TTN_ERR_UNSUPPORTED, "ttn_add: 2^31 or more fibres in one core (32-bit element indices)");
     hipLaunchKernelGGL(k_ranks_add, dim3(x->batch), dim3(64), 0, g_stream, z->dev(), x->dev(), y->dev());
-    hipLaunchKernelGGL(k_add, stream_grid(maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), z->dev());
+    bool qtt = true;
+    for (int k = 0; k < d; ++k) qtt = qtt && x->dims[k] == 2;
+    hipLaunchKernelGGL(k_add, stream_grid(qtt ? (maxpq + TTN_ADD_K - 1) / TTN_ADD_K : maxpq, d, x->batch), dim3(TTN_STREAM_TB), 0, g_stream, x->dev(), y->dev(), z->dev());
     HIPCHK(hipGetLastError());
     z->bound = zb;
     std::fill(z->ot.begin(), z->ot.end(), 0);

@@ -5,6 +5,8 @@
 #include "ttn_common.h"
 
 #define TTN_STREAM_TB 256
+#define TTN_ADD_K 4                       // columns per thread in k_add (n = 2)
+#define TTN_HAD_K 4                       // right indices per thread in k_hadamard (n = 2)
 
 // ---------------------------------------------------------------------------------------------
 // rank bookkeeping (Int64, bit-exact): tiny one-block kernels
@@ -156,20 +158,39 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_hadamard(TTDev x, TTDev y, TT
     // 32-bit index arithmetic (a core has fewer than 2^31 fibres: the host refuses larger ones): the 64-bit divisions of the first
     // version were most of the kernel's instructions, and the kernel was bound by them, not by HBM
     const unsigned int utotal = (unsigned int)total, uP = (unsigned int)P;
+    if (n == 2) {
+        // One thread = one left index p and TTN_HAD_K consecutive right indices q: the six integer divisions of an output fibre are
+        // paid once per K fibres (the right pair (by, bx) advances by increment), the 2 K loads are in flight together, and for every
+        // j the lanes of a wave still write consecutive p: 16 bytes per lane, 1 KB per wave, coalesced.  (One fibre per thread: 0.36
+        // of 8 TB/s — the kernel was bound by its index arithmetic and by the latency of two dependent loads per 16 bytes written.)
+        const unsigned int uQ = (unsigned int)Q, qgroups = (uQ + TTN_HAD_K - 1) / TTN_HAD_K, items = uP * qgroups;
+        typedef double d2v_t __attribute__((ext_vector_type(2)));
+        for (unsigned int it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
+            const unsigned int p = it % uP, qg = it / uP;
+            const unsigned int ay = p % (unsigned int)ryl, ax = p / (unsigned int)ryl;
+            const unsigned int q0 = qg * TTN_HAD_K;
+            unsigned int by = q0 % (unsigned int)ryr, bx = q0 / (unsigned int)ryr;
+            d2v_t xv[TTN_HAD_K], yv[TTN_HAD_K];
+#pragma unroll
+            for (int j = 0; j < TTN_HAD_K; ++j) {
+                const bool in = q0 + j < uQ;
+                xv[j] = in ? *reinterpret_cast<const d2v_t*>(Xk + 2 * (ax + (long long)rxl * bx)) : (d2v_t){0.0, 0.0};
+                yv[j] = in ? *reinterpret_cast<const d2v_t*>(Yk + 2 * (ay + (long long)ryl * by)) : (d2v_t){0.0, 0.0};
+                if (++by == (unsigned int)ryr) { by = 0; ++bx; }
+            }
+#pragma unroll
+            for (int j = 0; j < TTN_HAD_K; ++j)
+                if (q0 + j < uQ) __builtin_nontemporal_store(xv[j] * yv[j], reinterpret_cast<d2v_t*>(Zk + 2 * ((long long)p + (long long)uP * (q0 + j))));
+        }
+        return;
+    }
     for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < utotal; e += gridDim.x * blockDim.x) {
         const unsigned int p = e % uP, q = e / uP;
         const unsigned int ay = p % (unsigned int)ryl, ax = p / (unsigned int)ryl, by = q % (unsigned int)ryr, bx = q / (unsigned int)ryr;
         const double* xs = Xk + (long long)n * (ax + (long long)rxl * bx);
         const double* ys = Yk + (long long)n * (ay + (long long)ryl * by);
         double* zo = Zk + (long long)n * e;
-        if (n == 2) {
-            double2 o;
-            o.x = xs[0] * ys[0];
-            o.y = xs[1] * ys[1];
-            *reinterpret_cast<double2*>(zo) = o;
-        } else {
-            for (int s = 0; s < n; ++s) zo[s] = xs[s] * ys[s];
-        }
+        for (int s = 0; s < n; ++s) zo[s] = xs[s] * ys[s];
     }
 }
 
@@ -188,6 +209,32 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_add(TTDev x, TTDev y, TTDev z
     const double* Yk = y.data + (long long)b * y.stride + y.off[k];
     double* Zk = z.data + (long long)b * z.stride + z.off[k];
     const unsigned int utotal = (unsigned int)total;
+    if (n == 2) {
+        // one thread = one row a and TTN_ADD_K consecutive columns c of the output core: two integer divisions per K fibres, the loads of
+        // the K source fibres in flight together, per j the lanes of a wave write consecutive rows (coalesced 16-byte stores, non-temporal)
+        typedef double d2v_t __attribute__((ext_vector_type(2)));
+        const unsigned int uzl = (unsigned int)zl, uzr = (unsigned int)zr, cgroups = (uzr + TTN_ADD_K - 1) / TTN_ADD_K, items = uzl * cgroups;
+        for (unsigned int it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
+            const int a = (int)(it % uzl), c0 = (int)(it / uzl) * TTN_ADD_K;
+            d2v_t v[TTN_ADD_K];
+#pragma unroll
+            for (int j = 0; j < TTN_ADD_K; ++j) {
+                const int c = c0 + j;
+                const double* src = nullptr;
+                if (c < zr) {
+                    if (k == 0) src = (c < rxr) ? Xk + 2LL * ((long long)rxl * c) : Yk + 2LL * ((long long)ryl * (c - rxr));
+                    else if (k == d - 1) src = (a < rxl) ? Xk + 2LL * a : Yk + 2LL * (a - rxl);
+                    else if (a < rxl && c < rxr) src = Xk + 2LL * (a + (long long)rxl * c);
+                    else if (a >= rxl && c >= rxr) src = Yk + 2LL * ((a - rxl) + (long long)ryl * (c - rxr));
+                }
+                v[j] = src ? *reinterpret_cast<const d2v_t*>(src) : (d2v_t){0.0, 0.0};
+            }
+#pragma unroll
+            for (int j = 0; j < TTN_ADD_K; ++j)
+                if (c0 + j < zr) __builtin_nontemporal_store(v[j], reinterpret_cast<d2v_t*>(Zk + 2LL * ((long long)a + (long long)zl * (c0 + j))));
+        }
+        return;
+    }
     for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < utotal; e += gridDim.x * blockDim.x) {
         const int a = (int)(e % (unsigned int)zl), c = (int)(e / (unsigned int)zl);
         const double* src = nullptr;
@@ -214,6 +261,32 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_add(TTDev x, TTDev y, TTDev z
     }
 }
 
+// y = f * x (or x, or zero) over t2 16-byte elements: four loads in flight per thread and trip, non-temporal stores (the output is
+// read by a later kernel, not by this one).  One load -> one store per trip left the copy at 4.85 TB/s; k_hadamard's stores reach 5.5.
+__device__ __forceinline__ void stream_scale_copy(const double* Xk, double* Yk, long long t2, double f, bool scale_it, bool zero) {
+    typedef double d2v_t __attribute__((ext_vector_type(2)));
+    const d2v_t* X2 = reinterpret_cast<const d2v_t*>(Xk);
+    d2v_t* Y2 = reinterpret_cast<d2v_t*>(Yk);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double g = zero ? 0.0 : (scale_it ? f : 1.0);
+    for (; e + 3 * stride < t2; e += 4 * stride) {
+        d2v_t v0, v1, v2, v3;
+        if (zero) { v0 = v1 = v2 = v3 = (d2v_t){0.0, 0.0}; }
+        else { v0 = X2[e]; v1 = X2[e + stride]; v2 = X2[e + 2 * stride]; v3 = X2[e + 3 * stride]; }
+        if (scale_it && !zero) { v0 *= g; v1 *= g; v2 *= g; v3 *= g; }
+        __builtin_nontemporal_store(v0, &Y2[e]);
+        __builtin_nontemporal_store(v1, &Y2[e + stride]);
+        __builtin_nontemporal_store(v2, &Y2[e + 2 * stride]);
+        __builtin_nontemporal_store(v3, &Y2[e + 3 * stride]);
+    }
+    for (; e < t2; e += stride) {
+        d2v_t v = zero ? (d2v_t){0.0, 0.0} : X2[e];
+        if (scale_it && !zero) v *= g;
+        __builtin_nontemporal_store(v, &Y2[e]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // scalar *: copy every core, scale core `which` by a (src/tt_operations.jl:256-266); zero==1 -> all-zero train
 // ---------------------------------------------------------------------------------------------
@@ -228,13 +301,7 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_scale(TTDev x, TTDev y, doubl
     const double f = (k == which) ? a : 1.0;
     // 16 bytes per lane and trip (every slot is 16-byte aligned), a scalar tail for an odd count
     const long long t2 = total >> 1;
-    const double2* X2 = reinterpret_cast<const double2*>(Xk);
-    double2* Y2 = reinterpret_cast<double2*>(Yk);
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < t2; e += (long long)gridDim.x * blockDim.x) {
-        double2 v = zero ? double2{0.0, 0.0} : X2[e];
-        if (k == which && !zero) { v.x *= f; v.y *= f; }
-        Y2[e] = v;
-    }
+    stream_scale_copy(Xk, Yk, t2, f, k == which, zero != 0);
     if ((total & 1) && blockIdx.x == 0 && threadIdx.x == 0) Yk[total - 1] = zero ? 0.0 : ((k == which) ? f * Xk[total - 1] : Xk[total - 1]);
 }
 
@@ -248,13 +315,7 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_scale_batch(TTDev x, TTDev y,
     double* Yk = y.data + (long long)b * y.stride + y.off[k];
     const double f = a[b];
     const long long t2 = total >> 1;
-    const double2* X2 = reinterpret_cast<const double2*>(Xk);
-    double2* Y2 = reinterpret_cast<double2*>(Yk);
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < t2; e += (long long)gridDim.x * blockDim.x) {
-        double2 v = (f == 0.0) ? double2{0.0, 0.0} : X2[e];
-        if (k == which && f != 0.0) { v.x *= f; v.y *= f; }
-        Y2[e] = v;
-    }
+    stream_scale_copy(Xk, Yk, t2, f, k == which, f == 0.0);
     if ((total & 1) && blockIdx.x == 0 && threadIdx.x == 0) Yk[total - 1] = (f == 0.0) ? 0.0 : ((k == which) ? f * Xk[total - 1] : Xk[total - 1]);
 }
 
