@@ -560,7 +560,19 @@ int ttn_apply(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y) {
     const int lds_a = amax_ <= TTN_APPLY_LDS_DOUBLES ? (int)amax_ : 0;
     const int lds_rl = rlmax_ <= TTN_APPLY_MAX_RL ? (int)rlmax_ : 0;
     const size_t apply_lds = sizeof(double) * (size_t)((lds_a + 1) & ~1) + sizeof(double) * 2 * (size_t)(TTN_STREAM_TB / 64) * lds_rl * 64;
-    hipLaunchKernelGGL(k_apply, stream_grid(maxfib, d, x->batch), dim3(TTN_STREAM_TB), apply_lds, g_stream, A->dev(), x->dev(), y->dev(), lds_a, lds_rl);
+    // grid: output rows x groups of TTN_APPLY_K output columns when every site has n = 2 and the operator cores fit the LDS (the mapping
+    // of k_apply's fast path), input fibres otherwise
+    long long apply_items = maxfib;
+    {
+        bool qtt = lds_a > 0;
+        for (int k = 0; k < d; ++k) qtt = qtt && x->dims[k] == 2;
+        if (qtt) {
+            apply_items = 0;
+            for (int k = 0; k < d; ++k)
+                apply_items = std::max<long long>(apply_items, (long long)A->rks[k] * x->bound[k] * (((long long)A->rks[k + 1] * x->bound[k + 1] + TTN_APPLY_K - 1) / TTN_APPLY_K));
+        }
+    }
+    hipLaunchKernelGGL(k_apply, stream_grid(apply_items, d, x->batch), dim3(TTN_STREAM_TB), apply_lds, g_stream, A->dev(), x->dev(), y->dev(), lds_a, lds_rl);
     HIPCHK(hipGetLastError());
     for (int m = 0; m <= d; ++m) y->bound[m] = A->rks[m] * x->bound[m];
     std::fill(y->ot.begin(), y->ot.end(), 0);     // zeros_tt (tt_operations.jl:103)

@@ -5,8 +5,9 @@
 #include "ttn_common.h"
 
 #define TTN_STREAM_TB 256
-#define TTN_ADD_K 4                       // columns per thread in k_add (n = 2)
-#define TTN_HAD_K 4                       // right indices per thread in k_hadamard (n = 2)
+#define TTN_APPLY_K 4                     // output columns per thread in k_apply (n = 2); measured at B = 1024: K = 1 0.36, 2 0.53, 3 0.58, 4 0.635, 5 0.62, 6 0.54, 8 0.55, 12 0.51 of 8 TB/s
+#define TTN_ADD_K 4                       // columns per thread in k_add (n = 2): 2 0.61, 4 0.65, 8 0.62
+#define TTN_HAD_K 2                       // right indices per thread in k_hadamard (n = 2): 2 0.74, 4 0.69, 8 0.62
 
 // ---------------------------------------------------------------------------------------------
 // rank bookkeeping (Int64, bit-exact): tiny one-block kernels
@@ -60,10 +61,11 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_apply(TTODev A, TTDev x, TTDe
     const int rl = (int)xr[k], rr = (int)xr[k + 1];
     const long long total = (long long)rl * rr;                       // input fibres
     const long long first = (long long)blockIdx.x * blockDim.x;
-    if (first >= total) return;
     const double* Ak = A.data + A.off[k];
     const int asz = n * n * Rl * Rr;
     const bool in_lds = asz <= lds_a;
+    // (the output-row mapping below counts rows x column groups, the mappings after it input fibres: a block beyond the work of its mapping leaves)
+    if ((n == 2 && in_lds) ? first >= (long long)Rl * rl * (((long long)Rr * rr + TTN_APPLY_K - 1) / TTN_APPLY_K) : first >= total) return;
     if (in_lds) {
         for (int e = threadIdx.x; e < asz; e += blockDim.x) As[e] = Ak[e];
         __syncthreads();
@@ -72,6 +74,38 @@ __global__ void __launch_bounds__(TTN_STREAM_TB) k_apply(TTODev A, TTDev x, TTDe
     const double* Xk = x.data + (long long)b * x.stride + x.off[k];
     double* Yk = y.data + (long long)b * y.stride + y.off[k];
     const long long P = (long long)Rl * rl;                           // left rank of Y
+#ifndef TTN_APPLY_BY_INPUT_FIBRE
+    // n = 2, operator core in LDS: one thread = one OUTPUT row p = a' + Rl v' and TTN_APPLY_K consecutive output columns c = a + Rr v
+    // (the layout of k_hadamard: Y_k is the Kronecker product of the operator core and X_k, slice by slice).  For every j the lanes of
+    // a wave write consecutive rows: 16 bytes per lane, coalesced, non-temporal; the index arithmetic is paid once per K fibres, the
+    // column pair (a, v) advances by increment, the input fibre is reloaded only when v changes (every Rr columns; the Rl lanes that
+    // share it hit the same line).  Replaces the wave-level LDS transpose of the input-fibre mapping (4.1 TB/s; this form: see §4.1).
+    if (n == 2 && in_lds) {
+        typedef double d2v_t __attribute__((ext_vector_type(2)));
+        const unsigned int uP = (unsigned int)P, uQ = (unsigned int)((long long)Rr * rr), cgroups = (uQ + TTN_APPLY_K - 1) / TTN_APPLY_K, items = uP * cgroups;
+        for (unsigned int it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
+            const unsigned int p = it % uP, c0 = (it / uP) * TTN_APPLY_K;
+            const unsigned int al = p % (unsigned int)Rl, vl = p / (unsigned int)Rl;
+            unsigned int ar = c0 % (unsigned int)Rr, vr = c0 / (unsigned int)Rr;
+            d2v_t o[TTN_APPLY_K];
+            d2v_t xv = (c0 < uQ) ? *reinterpret_cast<const d2v_t*>(Xk + 2 * ((long long)vl + (long long)rl * vr)) : (d2v_t){0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < TTN_APPLY_K; ++j) {
+                const double* ap = As + 4 * ((long long)al + (long long)Rl * ar);      // A[i, j, a', a] at i + 2 j + 4 (a' + Rl a)
+                o[j].x = fma(ap[2], xv.y, ap[0] * xv.x);
+                o[j].y = fma(ap[3], xv.y, ap[1] * xv.x);
+                if (++ar == (unsigned int)Rr) {
+                    ar = 0; ++vr;
+                    if (j + 1 < TTN_APPLY_K && c0 + j + 1 < uQ) xv = *reinterpret_cast<const d2v_t*>(Xk + 2 * ((long long)vl + (long long)rl * vr));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TTN_APPLY_K; ++j)
+                if (c0 + j < uQ) __builtin_nontemporal_store(o[j], reinterpret_cast<d2v_t*>(Yk + 2 * ((long long)p + (long long)uP * (c0 + j))));
+        }
+        return;
+    }
+#endif
 #ifndef TTN_APPLY_NO_TRANSPOSE
     // n = 2 and rl a multiple of 64 (the interior cores): a wave's 64 input fibres are 64 consecutive left indices of ONE
     // right index, so for every operator right index `ar` its Rl*64 output fibres are one contiguous run of Rl*64*16 bytes.
