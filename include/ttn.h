@@ -214,6 +214,14 @@ int ttn_tdvp_apply_h2(int cplx, int64_t batch, int64_t Dl, int64_t d1, int64_t d
 int ttn_tdvp_contract_f64(int op, int cplx, int64_t batch, const int64_t* dims7, const double* FL, const double* FR, const double* X, const double* M1,
                           const double* M2, double* out, int m_shared);
 
+/* --- dense moves of the TDVP sweeps on one local matrix (src/solvers/tdvp.jl:76-80, :120-126: qr(Aqr), qr(A'); :252, :276: the svd inside
+ * _svdtrunc), Float64 (cplx = 0) or ComplexF64 (cplx = 1, interleaved), column-major, DEVICE pointers, the library's stream.
+ * ttn_dense_qr: Householder as LAPACK's geqr2 + org2r: A (m x n, overwritten) -> Q (m x r), R (r x n), r = min(m, n); asynchronous.
+ * ttn_dense_svd: one-sided Jacobi, m >= n (pass the conjugate transpose otherwise): A (overwritten) -> U (m x n), s (n, descending),
+ * Vh (n x n), A = U diag(s) Vh; synchronises (the caller reads s to choose the rank); TTN_ERR_NO_CONVERGENCE after 60 sweeps. */
+int ttn_dense_qr(int cplx, int64_t m, int64_t n, double* A, double* Q, double* R);
+int ttn_dense_svd(int cplx, int64_t m, int64_t n, double* A, double* U, double* s, double* Vh);
+
 /* fused convenience for the benchmark op  tt_compress!(A*x, max_bond)  (src/solvers/euler.jl:55) */
 int ttn_apply_compress(ttn_tto_t A, ttn_tt_t x, ttn_tt_t y, int64_t max_bond, double truncerr, int64_t sweeps);
 

@@ -85,6 +85,8 @@ SIGNATURES = {
     "ttn_tdvp_update_left_env": (C.c_int, [C.c_int, i64, i64, i64, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ttn_tdvp_update_right_env": (C.c_int, [C.c_int, i64, i64, i64, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ttn_tdvp_apply_h2": (C.c_int, [C.c_int, i64, i64, i64, i64, i64, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "ttn_dense_qr": (C.c_int, [C.c_int, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ttn_dense_svd": (C.c_int, [C.c_int, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ttn_tdvp_contract_f64": (C.c_int, [C.c_int, C.c_int, i64, p_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ttn_selftest_eig128": (C.c_int, [C.c_void_p, i64, i64, i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ttn_add": (C.c_int, [handle, handle, handle]),

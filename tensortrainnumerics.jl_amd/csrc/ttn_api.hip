@@ -12,6 +12,7 @@
 #include "ttn_als_grid.h"
 #include "ttn_eig_kernels.h"
 #include "ttn_tdvp_kernels.h"
+#include "ttn_densefact_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1936,6 +1937,43 @@ int ttn_tdvp_apply_h2(int cplx, int64_t batch, int64_t Dl, int64_t d1, int64_t d
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     return tdvp_launch(4, cplx, batch, Dl, d1, Dr, a, b, c, d2, FL, FR, AAC, M1, M2, HAAC, m_shared, false);
 }
+// ---- dense QR / SVD of one local matrix, real or complex, device pointers (csrc/ttn_densefact_kernels.h) ----
+int ttn_dense_qr(int cplx, int64_t m, int64_t n, double* A, double* Q, double* R) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!A || !Q || !R || m < 1 || n < 1) return fail(TTN_ERR_ARG, "ttn_dense_qr: bad argument");
+    if (m > (1 << 20) || n > (1 << 20)) return fail(TTN_ERR_UNSUPPORTED, "ttn_dense_qr: matrix too large");
+    const int64_t r = std::min(m, n);
+    int rc = ensure_scratch(sizeof(double) * 2 * (size_t)r + 64);
+    if (rc) return rc;
+    if (cplx) hipLaunchKernelGGL(k_dense_qr<true>, dim3(1), dim3(TTN_DF_WG), 0, g_stream, (int)m, (int)n, A, Q, R, (double*)g_scratch);
+    else hipLaunchKernelGGL(k_dense_qr<false>, dim3(1), dim3(TTN_DF_WG), 0, g_stream, (int)m, (int)n, A, Q, R, (double*)g_scratch);
+    HIPCHK(hipGetLastError());
+    return TTN_OK;
+}
+int ttn_dense_svd(int cplx, int64_t m, int64_t n, double* A, double* U, double* s, double* Vh) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    NEED_INIT();
+    if (!A || !U || !s || !Vh || m < 1 || n < 1) return fail(TTN_ERR_ARG, "ttn_dense_svd: bad argument");
+    if (m < n) return fail(TTN_ERR_ARG, "ttn_dense_svd: m >= n required (pass the conjugate transpose)");
+    if (m > (1 << 20) || n > 4096) return fail(TTN_ERR_UNSUPPORTED, "ttn_dense_svd: matrix too large");
+    const size_t w = cplx ? 2 : 1;
+    const size_t vw = sizeof(double) * w * (size_t)n * n, dwb = sizeof(double) * (size_t)n;
+    int rc = ensure_scratch(vw + dwb + sizeof(int) * ((size_t)n + 2) + 64);
+    if (rc) return rc;
+    double* Vw = (double*)g_scratch;
+    double* dw = Vw + w * (size_t)n * n;
+    int* iw = reinterpret_cast<int*>(dw + n);
+    if (cplx) hipLaunchKernelGGL(k_dense_svd<true>, dim3(1), dim3(TTN_DF_WG), 0, g_stream, (int)m, (int)n, A, U, s, Vh, Vw, dw, iw, 60);
+    else hipLaunchKernelGGL(k_dense_svd<false>, dim3(1), dim3(TTN_DF_WG), 0, g_stream, (int)m, (int)n, A, U, s, Vh, Vw, dw, iw, 60);
+    HIPCHK(hipGetLastError());
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, iw + n, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    if (flag) return fail(TTN_ERR_NO_CONVERGENCE, "ttn_dense_svd: the Jacobi sweeps did not converge");
+    return TTN_OK;
+}
+
 // host-array forms (what a `ccall` from tdvp1sweep! / tdvp2sweep! binds): op = 0 applyH1, 1 applyH0, 2 update_left_env,
 // 3 update_right_env, 4 applyH2; dims = {Dl, d (d1), Dr, a, b, c, d2} with the meaning of the device forms above
 int ttn_tdvp_contract_f64(int op, int cplx, int64_t batch, const int64_t* dims7, const double* FL, const double* FR, const double* X, const double* M1,

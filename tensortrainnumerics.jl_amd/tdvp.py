@@ -238,6 +238,42 @@ def _d_applyH2(AAC, FL, FR, M1, M2):
     return out
 
 
+def _qr_j(Mt):
+    """Thin QR of a Julia matrix (m x n, column-major) held as the contiguous torch tensor Mt of shape (n, m): returns (Qt, Rt), the
+    column-major Q (m x r) and R (r x n) as torch tensors of shapes (r, m) and (n, r) — csrc/ttn_densefact_kernels.h (Householder,
+    LAPACK's conventions), real or complex."""
+    torch, _ = _dev()
+    n, m = Mt.shape
+    r = min(m, n)
+    W = _own(Mt).clone()
+    Qt = torch.empty((r, m), dtype=Mt.dtype, device=Mt.device)
+    Rt = torch.empty((n, r), dtype=Mt.dtype, device=Mt.device)
+    _lib.check(_lib.lib().ttn_dense_qr(_cplx(W), m, n, _p(W), _p(Qt), _p(Rt)))
+    return Qt, Rt
+
+
+def _svd_j(Mt):
+    """Thin SVD X = U diag(s) Vt of a Julia matrix X (m x n) held as the torch tensor Mt of shape (n, m): returns (Ut, s, Vtt) with
+    U (m x k) as a tensor of shape (k, m), Vt (k x n) as a tensor of shape (n, k), k = min(m, n), s on the HOST (descending) —
+    one-sided Jacobi (csrc/ttn_densefact_kernels.h), on the matrix or on its conjugate transpose, whichever has fewer columns."""
+    torch, _ = _dev()
+    n, m = Mt.shape
+    real_dt = torch.float64
+    if m >= n:
+        W = _own(Mt).clone()
+        Ut = torch.empty((n, m), dtype=Mt.dtype, device=Mt.device)
+        Vtt = torch.empty((n, n), dtype=Mt.dtype, device=Mt.device)
+        sd = torch.empty((n,), dtype=real_dt, device=Mt.device)
+        _lib.check(_lib.lib().ttn_dense_svd(_cplx(W), m, n, _p(W), _p(Ut), _p(sd), _p(Vtt)))
+        return Ut, sd, Vtt
+    W = _own(Mt.transpose(0, 1).conj()).clone()                   # X^H (n x m) as a tensor of shape (m, n)
+    U2 = torch.empty((m, n), dtype=Mt.dtype, device=Mt.device)      # U' (n x m)
+    V2 = torch.empty((m, m), dtype=Mt.dtype, device=Mt.device)      # V'h (m x m)
+    sd = torch.empty((m,), dtype=real_dt, device=Mt.device)
+    _lib.check(_lib.lib().ttn_dense_svd(_cplx(W), n, m, _p(W), _p(U2), _p(sd), _p(V2)))
+    return _own(V2.transpose(0, 1).conj()), sd, _own(U2.transpose(0, 1).conj())      # U = V'h^H, Vt = U'^H
+
+
 def exponentiate(Hfun, t, x, krylovdim: int = 30, tol: float = 1.0e-12, maxiter: int = 100):
     """y = exp(t H) x for a Hermitian H given as a function on device arrays of x's shape — KrylovKit.exponentiate(H, t, x;
     ishermitian = true) with its defaults (tdvp.jl:68, :88 ...): Lanczos with full reorthogonalisation up to `krylovdim` vectors, the
@@ -348,24 +384,24 @@ def _sweep1(S: _State, dt, **kw):
     for k in range(N - 1):
         AC = exponentiate(lambda x: _d_applyH1(x, F[k], F[k + 2], M[k]), tm, AC, **kw)
         Dl, d, Dr = _jshape(AC)
-        Q, R = torch.linalg.qr(AC.reshape(Dr, d * Dl).transpose(0, 1), mode="reduced")      # Aqr = reshape(AC, Dl d, Dr)
+        Qt, Rt = _qr_j(AC.reshape(Dr, d * Dl))                                               # Aqr = reshape(AC, Dl d, Dr)
         r = min(Dl * d, Dr)
-        AL = _own(Q[:, :r].transpose(0, 1)).reshape(r, d, Dl)
+        AL = Qt.reshape(r, d, Dl)                                                            # reshape(Qthin, Dl, d, r)
         A[k] = AL
         F[k + 1] = _d_left_env(AL, M[k], F[k])
-        Cm = _own(R[:r, :].transpose(0, 1))                                           # C = Rthin (r x Dr), stored (Dr, r)
+        Cm = Rt                                                                              # C = Rthin (r x Dr), stored (Dr, r)
         Cm = exponentiate(lambda x: _d_applyH0(x, F[k + 1], F[k + 2]), tp, Cm, **kw)
         AC = _own(torch.matmul(A[k + 1], Cm))                                         # AC[α,s,β] = C[α,γ] A_{k+1}[γ,s,β]
     k = N - 1
     AC = exponentiate(lambda x: _d_applyH1(x, F[k], F[k + 2], M[k]), tm, AC, **kw)
     for k in range(N - 2, -1, -1):
         Dl, d, Dr = _jshape(AC)
-        Q, R = torch.linalg.qr(AC.reshape(Dr * d, Dl).conj(), mode="reduced")                # qr(A'), A = reshape(AC, Dl, d Dr)
+        Qt, Rt = _qr_j(_own(AC.reshape(Dr * d, Dl).transpose(0, 1).conj()))                  # qr(A'), A = reshape(AC, Dl, d Dr)
         r = min(Dl, d * Dr)
-        A_r = _own(Q[:, :r].conj()).reshape(Dr, d, r)                                 # reshape(Qthin', r, d, Dr)
+        A_r = _own(Qt.transpose(0, 1).conj()).reshape(Dr, d, r)                              # reshape(Qthin', r, d, Dr)
         A[k + 1] = A_r
         F[k + 2] = _d_right_env(A_r, M[k + 1], F[k + 3])
-        Lm = _own(R[:r, :].conj())                                                    # L = Rthin' (Dl x r), stored (r, Dl)
+        Lm = _own(Rt.transpose(0, 1).conj())                                                 # L = Rthin' (Dl x r), stored (r, Dl)
         Lm = exponentiate(lambda x: _d_applyH0(x, F[k + 1], F[k + 2]), tp, Lm, **kw)
         AC = _own(torch.tensordot(Lm, A[k], dims=([1], [0])))                         # AC[α,s,β] = A_k[α,s,γ] C[γ,β]
         AC = exponentiate(lambda x: _d_applyH1(x, F[k], F[k + 2], M[k]), tm, AC, **kw)
@@ -382,9 +418,9 @@ def _sweep2(S: _State, dt, max_bond=2 ** 62, truncerr=0.0, **kw):
 
     def split(AAC):
         Dl, d1, d2, Dr = _jshape(AAC)
-        U2, s, V2h = torch.linalg.svd(AAC.reshape(Dr * d2, d1 * Dl), full_matrices=False)   # the stored matrix is the transpose of reshape(AAC, Dl d1, d2 Dr)
-        r = _svd_rank(s.tolist(), max_bond, truncerr)
-        return (Dl, d1, d2, Dr), r, U2[:, :r], s[:r].to(AAC.dtype), V2h[:r, :]
+        Ut, sd, Vtt = _svd_j(AAC.reshape(Dr * d2, d1 * Dl))                                 # X = reshape(AAC, Dl d1, d2 Dr) = U S Vt
+        r = _svd_rank(sd.tolist(), max_bond, truncerr)
+        return (Dl, d1, d2, Dr), r, Vtt[:, :r], sd[:r].to(AAC.dtype), Ut[:r, :]              # (Vt^T: (d2 Dr) x r; U^T: r x (Dl d1))
 
     for k in range(N - 1):
         AAC = _own(torch.tensordot(A[k + 1], AC, dims=([2], [0])))                    # AAC[α,s1,s2,β] = AC[α,s1,γ] A_{k+1}[γ,s2,β]
@@ -465,10 +501,10 @@ def _orthogonalize_state(S: _State):
     A = S.A
     for k in range(S.N - 1, 0, -1):
         Dl, d, Dr = _jshape(A[k])
-        Q, R = torch.linalg.qr(A[k].reshape(Dr * d, Dl).conj(), mode="reduced")               # LQ of reshape(A_k, Dl, d Dr)
-        r = Q.shape[1]
-        A[k] = _own(Q.conj()).reshape(Dr, d, r)
-        A[k - 1] = _own(torch.tensordot(R[:r, :].conj(), A[k - 1], dims=([1], [0])))
+        Qt, Rt = _qr_j(_own(A[k].reshape(Dr * d, Dl).transpose(0, 1).conj()))                  # LQ of reshape(A_k, Dl, d Dr) = QR of its adjoint
+        r = Qt.shape[0]
+        A[k] = _own(Qt.transpose(0, 1).conj()).reshape(Dr, d, r)
+        A[k - 1] = _own(torch.tensordot(_own(Rt.transpose(0, 1).conj()), A[k - 1], dims=([1], [0])))
     return float(torch.linalg.vector_norm(A[0]))
 
 
