@@ -94,16 +94,19 @@ __device__ __forceinline__ void oramp_bwd_phase(double (&a)[ROWS], double tauv, 
         const bool mine = lane == k;
         const double w = -t * uk;
         const double ts = (lane > k && lane < rows) ? t * (s0 + s1) : 0.0;
-        const double cf = mine ? w - 1.0 : -ts;                           // lane k: a[i] = x_i, so a[i] + (w - 1) x_i = w x_i
+        // lane k: its column becomes w x (x = the reflector it holds); the other lanes: a - ts x.  One FMA with a per-lane coefficient and a
+        // per-lane "keep" factor on the addend — NOT a + (w - 1) x in lane k: w - 1 rounds away the low bits of a small w (|u_k| large:
+        // w = -t u_k ~ 1e-2), 1e-14 relative in the column and 1e-12 in Q^T Q after a few sites (found by the ragged-rank fuzz test)
+        const double cf = mine ? w : -ts, keep = mine ? 0.0 : 1.0;
 #pragma unroll
         for (int i = LO; i < ROWS; ++i) {
             const double xi = oramp_readlane(a[i], k);
             if (i < LO + CH) {
                 const double ui = (i > k) ? xi : 0.0;
-                const double u = fma(cf, ui, a[i]);
-                a[i] = (i == k) ? (mine ? fma(w, uk, 1.0) : fma(-ts, uk, a[i])) : u;
+                const double u = fma(cf, ui, keep * a[i]);
+                a[i] = (i == k) ? (mine ? fma(w, uk, 1.0) : fma(-ts, uk, a[i])) : ((i > k) ? u : a[i]);
             } else {
-                a[i] = fma(cf, xi, a[i]);
+                a[i] = fma(cf, xi, keep * a[i]);
             }
         }
     }

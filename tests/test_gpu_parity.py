@@ -341,6 +341,36 @@ def _ortho_checks(O_, got, x, center, tol=1e-12):
     assert worst < tol, worst
 
 
+def test_orthogonalize_fuzz_ragged_ranks(T):
+    """Forty QTT trains with random lengths (3..16), random bond ranks in 1..64 (wide, square and tall sites in any order, ranks that
+    are no multiples of anything) and random centres through the default dispatch (ramp kernel / 512-thread kernel / general route,
+    whichever each site belongs to), singly and as one ragged batch: ranks and gauge flags exact, tensor 1e-12, orthonormality 1e-12."""
+    rng = np.random.default_rng(4242)
+    for trial in range(40):
+        d = int(rng.integers(3, 17))
+        rks = [1] + [int(rng.integers(1, 65)) for _ in range(d - 1)] + [1]
+        x = O.rand_tt((2,) * d, rks, rng)                      # (rand_tt caps the ranks at what the dimensions allow)
+        center = int(rng.integers(1, d + 1))
+        xp = to_product(x)
+        _ortho_checks(O, T.orthogonalize(xp, i=center), xp, center)
+    # one batch, all trains with the same declared rank bound but different actual ranks (ragged)
+    d, B = 12, 24
+    bound = [1] + [64] * (d - 1) + [1]
+    trains = []
+    for b in range(B):
+        rks = [1] + [int(rng.integers(1, 65)) for _ in range(d - 1)] + [1]
+        trains.append(to_product(O.rand_tt((2,) * d, rks, rng)))
+    cap = bound                                                # (a capacity, not a rank profile: larger than any train's ranks)
+    dx = T.DeviceTT((2,) * d, cap, batch=B)
+    for b in range(B):
+        dx.upload(b, trains[b])
+    dy = T.DeviceTT((2,) * d, cap, batch=B)
+    for center in (1, 7):
+        T.device.orthogonalize(dx, center, dy)
+        for b in range(B):
+            _ortho_checks(O, dy.download(b), trains[b], center)
+
+
 def test_orthogonalize_hand_over_between_the_kernels(T, monkeypatch):
     """The rarely taken paths of the multi-launch form: (a) the 512-thread kernel takes nothing (TTN_ORTHO_CHOLQR=1 forbids its
     Cholesky-QR steps): the 1024-thread kernel resumes every train right behind the ramp kernel, from the compacted list; (b) a train
