@@ -341,6 +341,34 @@ def _ortho_checks(O_, got, x, center, tol=1e-12):
     assert worst < tol, worst
 
 
+def test_dot_and_streaming_ops_fuzz(T):
+    """Sixty random pairs of trains (2..14 sites of size 2, every fifth trial of size 3; independent ragged bond ranks) through dot,
+    +, hadamard, scalar * and tto * ttv with a random operator: the kernels rewritten in round 3 (K fibres per thread in add / hadamard /
+    apply, the LDS-resident dot) on shapes where nothing is a multiple of anything.  Ranks exact; cores of the HBM-bound ops entrywise
+    1e-13 / 1e-12 (they are copies and short sums), dot to 1e-12 of ||x|| ||y||."""
+    rng = np.random.default_rng(99)
+    for trial in range(60):
+        d = int(rng.integers(2, 15))
+        n = 2 if trial % 5 else 3
+        dims = (n,) * d
+        x = O.rand_tt(dims, [1] + [int(rng.integers(1, 40)) for _ in range(d - 1)] + [1], rng)
+        y = O.rand_tt(dims, [1] + [int(rng.integers(1, 40)) for _ in range(d - 1)] + [1], rng)
+        xp, yp = to_product(x), to_product(y)
+        assert abs(T.dot(xp, yp) - O.dot(x, y)) <= 1e-12 * math.sqrt(abs(O.dot(x, x)) * abs(O.dot(y, y)))
+        z, zref = T.add(xp, yp), O.add(x, y)
+        assert list(z.ttv_rks) == zref.ttv_rks and tt_rel_diff(to_oracle(z), zref) < 1e-13
+        xs = O.rand_tt(dims, [1] + [int(rng.integers(1, 9)) for _ in range(d - 1)] + [1], rng)
+        ys = O.rand_tt(dims, [1] + [int(rng.integers(1, 9)) for _ in range(d - 1)] + [1], rng)
+        h, href = T.hadamard(to_product(xs), to_product(ys)), O.hadamard(xs, ys)
+        assert list(h.ttv_rks) == href.ttv_rks
+        assert max(np.max(np.abs(np.asarray(a) - b)) for a, b in zip(h.ttv_vec, href.ttv_vec)) <= 1e-13 * max(np.max(np.abs(b)) for b in href.ttv_vec)
+        A = O.rand_tto(dims, int(rng.integers(1, 5)), rng)
+        ya, yref = T.apply(to_product(A), xp), O.apply(A, x)
+        assert list(ya.ttv_rks) == yref.ttv_rks
+        assert max(np.max(np.abs(np.asarray(a) - b)) for a, b in zip(ya.ttv_vec, yref.ttv_vec)) <= 1e-12 * max(np.max(np.abs(b)) for b in yref.ttv_vec)
+        assert tt_rel_diff(to_oracle(T.scale(-1.75, xp)), O.scale(-1.75, x)) < 1e-13
+
+
 def test_orthogonalize_fuzz_ragged_ranks(T):
     """Forty QTT trains with random lengths (3..16), random bond ranks in 1..64 (wide, square and tall sites in any order, ranks that
     are no multiples of anything) and random centres through the default dispatch (ramp kernel / 512-thread kernel / general route,
