@@ -20,8 +20,10 @@
 #include "ttn_ortho_kernels.h"
 
 #define O5_WG 512
-#define O5_POLISH_MAX 1.0e-5             // measured max |Q^T Q - I| up to which first-order second passes are taken (each squares the error) ...
-#define O5_POLISH_TRUST 1.0e-9           // ... and below which one pass is trusted without measuring again
+#define O5_POLISH_MAX 1.0e-9             // measured max |Q^T Q - I| up to which a first-order second pass is taken: cond(W) <~ 2e3.  Not more:
+                                         // Q L^T = W holds to eps cond (blocked substitution with inverted 16 x 16 diagonal blocks), and the
+                                         // tensor has to stay within 1e-12; a worse conditioned site goes to the Householder route
+#define O5_POLISH_TRUST 1.0e-9           // ... below which one pass is trusted without measuring again (it leaves O(64 E^2) <= 1e-16)
 #define O5_IMG(k, i) ((k) * 64 + ((i) ^ ((((k) & 1) << 4) | ((((k) >> 1) & 3) << 2))))      // element (row i, column k) of a 64 x 64 image
 #define O5_BUF 4096
 #define O5_T16 (2 * O5_BUF)                 // inverse of the current diagonal block, [row * 17 + col]
@@ -136,6 +138,59 @@ __device__ __forceinline__ void o5_apply(const mfma_acc_t (&src_)[4], mfma_acc_t
     }
 }
 
+// the A fragments of an accumulator tile: af[u] (lane (li, lk)) = T[row = li][col = 4 u + lk] (see o5_apply)
+__device__ __forceinline__ void o5_tile_frags(const mfma_acc_t& t_, double (&af)[4]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, rsel = li >> 2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int src = (((li & 3) << 4) | (4 * u + lk)) << 2;
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            union { double dd; int ii[2]; } in_, out_;
+            in_.dd = t_[r];
+            out_.ii[0] = __builtin_amdgcn_ds_bpermute(src, in_.ii[0]);
+            out_.ii[1] = __builtin_amdgcn_ds_bpermute(src, in_.ii[1]);
+            v[r] = out_.dd;
+        }
+        af[u] = rsel == 0 ? v[0] : (rsel == 1 ? v[1] : (rsel == 2 ? v[2] : v[3]));
+    }
+}
+
+// Q = W L^-T by BLOCKED SUBSTITUTION: out[c] = (W_c - sum_{a < c} out[a] L[c][a]^T) X_cc^T with the inverses X_cc of the 16 x 16 diagonal
+// blocks only.  The first version multiplied W by the explicit inverse of the whole L, assembled block-wise from the inverted
+// diagonal blocks: that inverse satisfies X L = I only to eps cond(L)^2 (the error of a diagonal block's inverse is multiplied by the
+// off-diagonal sums), so Q L^T = W held only to the level of the measured orthogonality defect — harmless below the acceptance bar,
+// but a step repaired by second passes (defect up to 1e-5) kept that error in the TENSOR (1.4e-10 found on trains with cond 1e3
+// sites).  Substitution uses the computed columns of Q themselves: Q L^T = W to eps cond(L_cc).  Same MFMA count (ten tile products
+// per wave), four dependent stages, and the off-diagonal blocks of the inverse are not needed at all.
+template <bool FULL>
+__device__ __forceinline__ void o5_trsm_apply(const mfma_acc_t (&w_)[4], mfma_acc_t (&out)[4], const lds_f64* Lg, const lds_f64* Xd, int nat, bool active) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    double afo[3][4];                                                   // the A fragments of the finished tiles out[0 .. 2]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        out[c] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+        if (!active || (!FULL && c >= nat)) continue;
+        mfma_acc_t acc = w_[c];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (a >= c) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)                                 // acc[rho][al'] -= out_a[rho][al] L[al'][al], al' in block c, al in block a
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-afo[a][u], Lg[O5_IMG(16 * a + 4 * u + lk, 16 * c + li)], acc, 0, 0, 0);
+        }
+        double af[4];
+        o5_tile_frags(acc, af);
+        mfma_acc_t o = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                                     // out_c[rho][al'] = sum_al acc[rho][al] X_cc[al'][al]
+            o = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], Xd[O5_IMG(16 * c + 4 * u + lk, 16 * c + li)], o, 0, 0, 0);
+        out[c] = o;
+        if (c < 3) o5_tile_frags(o, afo[c]);
+    }
+}
+
 // One site.  Returns false when the step is refused (bad pivot, or measured orthogonality above the bar): nothing in global memory
 // has been written then.  cur / first: the image ping-pong (see the kernel).  FULL: rl = rr = ynext = 64.
 // (out of line on purpose: inlined twice into the kernel's site loop the two instantiations cost 356 spilled VGPRs)
@@ -229,25 +284,6 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
             __syncthreads();
             O5S(10)
             if (uni32(flag[0])) { good = false; break; }
-            if (wave >= 4 && wave - 4 < jb) {
-                // row jb of X = L^-1 in the shadow of the panel (waves 1 .. 3): X[jb][c] = -X[jb][jb] sum_{kb = c}^{jb-1} L[jb][kb] X[kb][c].
-                // L's block row jb is final since the panel of step jb - 1, the rows of X above since their own steps.
-                const int ib = jb, jbk = wave - 4;
-                mfma_acc_t s_ = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
-                for (int kb = jbk; kb < ib; ++kb) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int kk = 4 * t + lk;                    // S[row][col] += L[16 ib + row][16 kb + kk] X[16 kb + kk][16 jbk + col]
-                        s_ = __builtin_amdgcn_mfma_f64_16x16x4f64(Gb[O5_IMG(16 * kb + kk, 16 * ib + li)], Li[O5_IMG(16 * jbk + li, 16 * kb + kk)], s_, 0, 0, 0);
-                    }
-                }
-                mfma_acc_t x_ = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r)                          // X_ij[row][col] = -sum_m X_ii[row][m] S[m][col]: S's registers are the B operand
-                    x_ = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[O5_IMG(16 * ib + 4 * r + lk, 16 * ib + li)], s_[r], x_, 0, 0, 0);
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Li[O5_IMG(16 * jbk + li, 16 * ib + lk + 4 * reg)] = -x_[reg];
-            }
             if (wave >= 1 && jb + wave < nat) {                         // panel: L[ib][jb] = G[ib][jb] X_jj^T
                 const int ib = jb + wave;
                 mfma_acc_t acc = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
@@ -285,9 +321,9 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
     }
     if (!good) return 0;                                            // refused: Rprev in global memory is intact, the state stays at site j
     O5S(4)
-    // ---- P5: Q_w[rho][al'] = sum_{al <= al'} W_w[rho][al] X[al'][al]; A fragments = W tiles transposed by ds_bpermute ----
+    // ---- P5: Q = W L^-T by blocked substitution (o5_trsm_apply: L's blocks from its image, the diagonal blocks' inverses from the other) ----
     mfma_acc_t q_[4];
-    o5_apply<FULL>(w_, q_, FLb, nat, tr < nbt);
+    o5_trsm_apply<FULL>(w_, q_, Gb, FLb, nat, tr < nbt);
     O5S(5)
     // ---- P6: the orthogonality of Q, measured: max |Q^T Q - I| over the lower triangle (the image that held L^-1 takes Q^T Q) ----
     auto measure = [&]() -> double {

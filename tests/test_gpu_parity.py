@@ -369,6 +369,24 @@ def test_dot_and_streaming_ops_fuzz(T):
         assert tt_rel_diff(to_oracle(T.scale(-1.75, xp)), O.scale(-1.75, x)) < 1e-13
 
 
+@pytest.mark.parametrize("eps", [1e-1, 3e-2, 1e-2, 3e-3, 1e-3, 1e-5])
+def test_orthogonalize_moderately_ill_conditioned_sites(T, eps):
+    """Trains whose tall sites have pairs of columns that agree up to eps (cond of the site matrices ~ 1 / eps): the range in which the
+    512-thread kernel accepts a Cholesky-QR step as it is (measured defect <= 2e-13), repairs it by a first-order second pass (<= 1e-9)
+    or refuses it and hands the train to the Householder route.  Whatever route a site takes, the TENSOR must stay within 1e-12 and
+    the cores orthonormal to 1e-12 — the first version multiplied by an explicitly assembled inverse of L and kept the orthogonality
+    defect (eps cond^2, up to 1e-10) as an error of Q R = W after the repair; found by sweeping eps, fixed by blocked substitution."""
+    rng = np.random.default_rng(11)
+    d, r = 14, 48
+    x = O.rand_tt((2,) * d, r, rng)
+    for k in (6, 7, 8):
+        c = x.ttv_vec[k]
+        c[:, 1::2, :] = c[:, 0::2, :][:, : c[:, 1::2, :].shape[1], :] + eps * c[:, 1::2, :]
+    xp = to_product(x)
+    _ortho_checks(O, T.orthogonalize(xp, i=1), xp, 1)
+    _ortho_checks(O, T.orthogonalize(xp, i=5), xp, 5)
+
+
 def test_orthogonalize_fuzz_ragged_ranks(T):
     """Forty QTT trains with random lengths (3..16), random bond ranks in 1..64 (wide, square and tall sites in any order, ranks that
     are no multiples of anything) and random centres through the default dispatch (ramp kernel / 512-thread kernel / general route,
