@@ -387,6 +387,37 @@ def test_orthogonalize_moderately_ill_conditioned_sites(T, eps):
     _ortho_checks(O, T.orthogonalize(xp, i=5), xp, 5)
 
 
+def test_apply_with_operator_cores_beyond_the_lds_staging_and_long_ragged_dots(T):
+    """tto * ttv with operator cores too large for k_apply's LDS staging (rank 40: 6400 doubles per core; the kernel's other mappings)
+    and dot on chains of up to 30 sites with independent ragged ranks up to 64 (the LDS-resident path) and up to 99 (the generic path),
+    singly and as one ragged batch."""
+    rng = np.random.default_rng(123)
+    for d, n, ro, rx in [(5, 2, 40, 9), (4, 2, 33, 64), (4, 3, 20, 7), (6, 2, 24, 16)]:
+        dims = (n,) * d
+        A, x = O.rand_tto(dims, ro, rng), O.rand_tt(dims, rx, rng)
+        ya, yref = T.apply(to_product(A), to_product(x)), O.apply(A, x)
+        assert list(ya.ttv_rks) == yref.ttv_rks
+        assert max(np.max(np.abs(np.asarray(a) - b)) for a, b in zip(ya.ttv_vec, yref.ttv_vec)) <= 1e-12 * max(np.max(np.abs(b)) for b in yref.ttv_vec)
+    for trial in range(30):
+        d = int(rng.integers(2, 31))
+        hi = 65 if trial % 3 else 100
+        x = O.rand_tt((2,) * d, [1] + [int(rng.integers(1, hi)) for _ in range(d - 1)] + [1], rng)
+        y = O.rand_tt((2,) * d, [1] + [int(rng.integers(1, hi)) for _ in range(d - 1)] + [1], rng)
+        x, y = O.scale(1 / O.norm(x), x), O.scale(1 / O.norm(y), y)
+        assert abs(T.dot(to_product(x), to_product(y)) - O.dot(x, y)) <= 1e-12
+    B, d = 40, 12
+    cap = [1] + [64] * (d - 1) + [1]
+    xs = [O.rand_tt((2,) * d, [1] + [int(rng.integers(1, 65)) for _ in range(d - 1)] + [1], rng) for _ in range(B)]
+    ys = [O.rand_tt((2,) * d, [1] + [int(rng.integers(1, 65)) for _ in range(d - 1)] + [1], rng) for _ in range(B)]
+    dx, dy = T.DeviceTT((2,) * d, cap, batch=B), T.DeviceTT((2,) * d, cap, batch=B)
+    for b in range(B):
+        dx.upload(b, to_product(xs[b]))
+        dy.upload(b, to_product(ys[b]))
+    got = T.device.dot(dx, dy)
+    for b in range(B):
+        assert abs(got[b] - O.dot(xs[b], ys[b])) <= 1e-12 * O.norm(xs[b]) * O.norm(ys[b])
+
+
 def test_orthogonalize_fuzz_ragged_ranks(T):
     """Forty QTT trains with random lengths (3..16), random bond ranks in 1..64 (wide, square and tall sites in any order, ranks that
     are no multiples of anything) and random centres through the default dispatch (ramp kernel / 512-thread kernel / general route,
