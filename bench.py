@@ -300,9 +300,17 @@ def drop_in_latency(T, d, r):
         t_apply.append(t1 - t0)
         t_comp.append(t2 - t1)
     ta, tc = min(t_apply[1:]), min(t_comp[1:])
+    t_fused = []
+    for _ in range(4):                              # ttn_apply_compress_f64: the same op in one call, A*x never crosses PCIe
+        t0 = time.perf_counter()
+        T.apply_compress(A, x, r)
+        t_fused.append(time.perf_counter() - t0)
+    tf = min(t_fused[1:])
     return {"what": "ttn_apply_f64 + ttn_compress_f64 on one train, host buffers in and out (PCIe-inclusive; best of 3 after one warm-up)",
             "ms_apply": round(ta * 1e3, 3), "ms_compress": round(tc * 1e3, 3), "ms_total": round((ta + tc) * 1e3, 3),
-            "value": round(d / (ta + tc), 1), "unit": "TT cores/s"}
+            "value": round(d / (ta + tc), 1), "unit": "TT cores/s",
+            "fused_call": {"what": "ttn_apply_compress_f64: tt_compress!(A * x, max_bond) as one stateless call", "ms_total": round(tf * 1e3, 3),
+                           "value": round(d / tf, 1)}}
 
 
 def pmc_busy_fractions():

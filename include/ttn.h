@@ -324,6 +324,15 @@ int ttn_compress_f64(int64_t d, const int64_t* dims, double* const* cores, int64
                      int64_t max_bond, double truncerr, int64_t sweeps);
 int ttn_bond_truncate_f64(int64_t d, const int64_t* dims, double* const* cores, int64_t* rks,
                           int64_t k, int64_t max_bond, double truncerr);
+/* op = x -> tt_compress!(A * x, max_bond) (src/solvers/euler.jl:55, the operator krylov_linsolve / the time steppers iterate) as ONE
+ * stateless call: A * x is never materialised, neither in HBM nor over PCIe (fused apply).  Y_cores[k] sized n_k * cap_k * cap_{k+1}
+ * with cap from ttn_apply_compress_rank_bound (the final ranks a sweep can leave: min(A_rks .* X_rks, max_bond, what the dimensions
+ * allow)); Y_rks (d + 1) receives the ranks, the cores come back compactly with those ranks. */
+int ttn_apply_compress_rank_bound(int64_t d, const int64_t* dims, const int64_t* A_rks, const int64_t* X_rks, int64_t max_bond, int64_t sweeps,
+                                  int64_t* cap);
+int ttn_apply_compress_f64(int64_t d, const int64_t* dims, const double* const* A_cores, const int64_t* A_rks,
+                           const double* const* X_cores, const int64_t* X_rks, double* const* Y_cores, int64_t* Y_rks,
+                           int64_t max_bond, double truncerr, int64_t sweeps);
 
 /* r_and_d_to_rks(rks, dims; rmax)   src/tt_tools.jl:407-425 (host-side integer helper, bit-exact) */
 int ttn_r_and_d_to_rks(int64_t d, const int64_t* dims, int64_t n_rks, const int64_t* rks, int64_t rmax, int64_t* out);

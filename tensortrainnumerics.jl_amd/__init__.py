@@ -10,7 +10,7 @@ from .constructors import (Delta, id_tto, portable_randn, qtt_cos, qtt_exp, qtt_
                            toeplitz_to_qtto, zeros_tt, zeros_tto)
 from .device import DeviceTT, DeviceTTO, StreamTimer
 from .qtt import bubble_sort_swaps, hadamard_ttm, reorder, reorder_op, reorder_perm, ttv_decomp
-from .tt import (TToperator, TTvector, _tt_bond_truncate_, add, add_, apply, div, dot, euclidean_distance, hadamard, norm,
+from .tt import (TToperator, TTvector, _tt_bond_truncate_, add, add_, apply, apply_compress, div, dot, euclidean_distance, hadamard, norm,
                  orthogonalize, r_and_d_to_rks, scale, sub, tt_compress_)
 
 __all__ = [n for n in dir() if not n.startswith("__")]

@@ -112,6 +112,8 @@ SIGNATURES = {
     "ttn_scale_f64": (C.c_int, [i64, p_i64, C.c_double, pp_f64, p_i64, p_i64, pp_f64, p_i64]),
     "ttn_orthogonalize_f64": (C.c_int, [i64, p_i64, pp_f64, p_i64, i64, pp_f64, p_i64, p_i64]),
     "ttn_compress_f64": (C.c_int, [i64, p_i64, pp_f64, p_i64, i64, C.c_double, i64]),
+    "ttn_apply_compress_rank_bound": (C.c_int, [i64, p_i64, p_i64, p_i64, i64, i64, p_i64]),
+    "ttn_apply_compress_f64": (C.c_int, [i64, p_i64, pp_f64, p_i64, pp_f64, p_i64, pp_f64, p_i64, i64, C.c_double, i64]),
     "ttn_bond_truncate_f64": (C.c_int, [i64, p_i64, pp_f64, p_i64, i64, i64, C.c_double]),
     "ttn_r_and_d_to_rks": (C.c_int, [i64, p_i64, i64, p_i64, i64, p_i64]),
 }

@@ -2116,6 +2116,44 @@ int ttn_compress_f64(int64_t d, const int64_t* dims, double* const* cores, int64
     return compress_host(d, dims, cores, rks, 0, max_bond, truncerr, sweeps);
 }
 
+// The Krylov operator of the reference in ONE stateless call: op = x -> tt_compress!(A * x, max_bond) (src/solvers/euler.jl:55).  A * x
+// is never materialised (fused apply, k_compress builds the merged matrices from x and A) — neither in HBM nor over PCIe: the host
+// hands over A and x, and receives the compressed train.  Y_cores[k] sized n_k * cap_k * cap_{k+1} with cap = min(A_rks .* X_rks,
+// max_bond-capped bounds) as ttn_apply_compress_rank_bound returns them; Y_rks receives the ranks.
+int ttn_apply_compress_rank_bound(int64_t d, const int64_t* dims, const int64_t* A_rks, const int64_t* X_rks, int64_t max_bond, int64_t sweeps,
+                                  int64_t* cap) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!dims || !A_rks || !X_rks || !cap || d < 1 || max_bond < 1 || sweeps < 1) return fail(TTN_ERR_ARG, "bad argument");
+    std::vector<int64_t> yr(d + 1), need, fin;
+    for (int64_t m = 0; m <= d; ++m) yr[m] = A_rks[m] * X_rks[m];
+    long long pm, qm;
+    rank_bounds((int)d, dims, yr.data(), max_bond, sweeps, 0, need, fin, pm, qm);
+    for (int64_t m = 0; m <= d; ++m) cap[m] = fin[m];
+    return TTN_OK;
+}
+int ttn_apply_compress_f64(int64_t d, const int64_t* dims, const double* const* A_cores, const int64_t* A_rks, const double* const* X_cores,
+                           const int64_t* X_rks, double* const* Y_cores, int64_t* Y_rks, int64_t max_bond, double truncerr, int64_t sweeps) {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int rc = auto_init(); if (rc) return rc;
+    if (!dims || !A_cores || !A_rks || !X_cores || !X_rks || !Y_cores || !Y_rks || d < 1) return fail(TTN_ERR_ARG, "bad argument");
+    if (sweeps < 1) return fail(TTN_ERR_SWEEPS, "sweeps must be >= 1");
+    if (max_bond < 1) return fail(TTN_ERR_ARG, "max_bond must be >= 1");
+    TmpTTO A; TmpTT x, y;
+    if ((rc = ttn_tto_create(d, dims, A_rks, A_cores, &A.h))) return rc;
+    if ((rc = ttn_tt_create(d, dims, X_rks, 1, &x.h))) return rc;
+    if ((rc = ttn_tt_upload(x.h, 0, X_cores, X_rks, nullptr))) return rc;
+    std::vector<int64_t> yr(d + 1), need, fin;
+    for (int64_t m = 0; m <= d; ++m) yr[m] = A_rks[m] * X_rks[m];
+    long long pm, qm;
+    rank_bounds((int)d, dims, yr.data(), max_bond, sweeps, 0, need, fin, pm, qm);
+    for (int64_t m = 0; m <= d; ++m) need[m] = std::max<int64_t>(need[m], yr[m]);
+    if ((rc = ttn_tt_create(d, dims, need.data(), 1, &y.h))) return rc;
+    if ((rc = ttn_apply_compress(A.h, x.h, y.h, max_bond, truncerr, sweeps))) return rc;
+    if ((rc = ttn_compress_status(y.h, nullptr))) return rc;
+    if ((rc = ttn_tt_ranks(y.h, 0, Y_rks, nullptr))) return rc;
+    return ttn_tt_download(y.h, 0, Y_cores);
+}
+
 int ttn_bond_truncate_f64(int64_t d, const int64_t* dims, double* const* cores, int64_t* rks, int64_t k, int64_t max_bond,
                           double truncerr) {
     std::lock_guard<std::recursive_mutex> lk(g_mu);

@@ -117,6 +117,28 @@ def apply(A: TToperator, v: TTvector) -> TTvector:
     return TTvector(d, Y, v.ttv_dims, yr, [0] * d)
 
 
+def apply_compress(A: TToperator, v: TTvector, max_bond: int, truncerr: float = 0.0, sweeps: int = 1) -> TTvector:
+    """tt_compress!(A * v, max_bond; truncerr, sweeps) — the operator krylov_linsolve and the time steppers iterate
+    (src/solvers/euler.jl:55) — as ONE stateless call (ttn_apply_compress_f64): A * v is never materialised, neither in HBM nor over
+    PCIe.  Same result as tt_compress_(apply(A, v), max_bond)."""
+    assert tuple(A.tto_dims) == tuple(v.ttv_dims), "Incompatible dimensions"
+    assert sweeps >= 1, "sweeps must be >= 1"
+    d = v.N
+    max_bond = int(min(max_bond, 2 ** 62))
+    L = _lib.lib()
+    cap = (C.c_int64 * (d + 1))()
+    _lib.check(L.ttn_apply_compress_rank_bound(d, _i64(v.ttv_dims), _i64(A.tto_rks), _i64(v.ttv_rks), max_bond, int(sweeps), cap))
+    bufs = [np.zeros(v.ttv_dims[j] * int(cap[j]) * int(cap[j + 1])) for j in range(d)]
+    rks = (C.c_int64 * (d + 1))()
+    Ac = [_f(c) for c in A.tto_vec]
+    Xc = [_f(c) for c in v.ttv_vec]
+    _lib.check(L.ttn_apply_compress_f64(d, _i64(v.ttv_dims), _ptrs(Ac), _i64(A.tto_rks), _ptrs(Xc), _i64(v.ttv_rks), _ptrs(bufs), rks,
+                                        max_bond, float(truncerr), int(sweeps)))
+    rk = [int(r) for r in rks]
+    cores = [np.reshape(bufs[j][: v.ttv_dims[j] * rk[j] * rk[j + 1]], (v.ttv_dims[j], rk[j], rk[j + 1]), order="F").copy(order="F") for j in range(d)]
+    return TTvector(d, cores, v.ttv_dims, rk, [0] * d)
+
+
 def dot(A: TTvector, B: TTvector) -> float:
     """dot(A, B) — src/tt_operations.jl:239-250."""
     assert tuple(A.ttv_dims) == tuple(B.ttv_dims), "TT dimensions are not compatible"

@@ -418,6 +418,21 @@ def test_apply_with_operator_cores_beyond_the_lds_staging_and_long_ragged_dots(T
         assert abs(got[b] - O.dot(xs[b], ys[b])) <= 1e-12 * O.norm(xs[b]) * O.norm(ys[b])
 
 
+@pytest.mark.parametrize("d,r,mb,seed", [(10, 8, 8, 0), (12, 16, 9, 1), (30, 64, 64, 2), (8, 5, 100, 3)])
+def test_stateless_apply_compress_is_compress_of_apply(T, d, r, mb, seed):
+    """ttn_apply_compress_f64 — op = x -> tt_compress!(A * x, max_bond) of src/solvers/euler.jl:55 as one stateless call — against the
+    oracle's tt_compress_(apply(A, x)) and against the two-call form of this library: ranks exact, tensor 1e-9 (typically 1e-13),
+    singular-value gauge as everywhere."""
+    rng = np.random.default_rng(900 + seed)
+    A = O.Delta(d)
+    x = O.rand_tt((2,) * d, r, rng)
+    ref = O.tt_compress_(O.apply(A, x), mb)
+    got = T.apply_compress(to_product(A), to_product(x), mb)
+    two = T.tt_compress_(T.apply(to_product(A), to_product(x)), mb)
+    assert list(got.ttv_rks) == ref.ttv_rks == list(two.ttv_rks)
+    assert tt_rel_diff(to_oracle(got), ref) < 1e-9 and tt_rel_diff(to_oracle(got), to_oracle(two)) < 1e-9
+
+
 def test_orthogonalize_fuzz_ragged_ranks(T):
     """Forty QTT trains with random lengths (3..16), random bond ranks in 1..64 (wide, square and tall sites in any order, ranks that
     are no multiples of anything) and random centres through the default dispatch (ramp kernel / 512-thread kernel / general route,
