@@ -20,9 +20,8 @@
 #include "ttn_ortho_kernels.h"
 
 #define O5_WG 512
-#define O5_POLISH_MAX 1.0e-9             // measured max |Q^T Q - I| up to which a first-order second pass is taken: cond(W) <~ 2e3.  Not more:
-                                         // Q L^T = W holds to eps cond (blocked substitution with inverted 16 x 16 diagonal blocks), and the
-                                         // tensor has to stay within 1e-12; a worse conditioned site goes to the Householder route
+#define O5_POLISH_MAX 1.0e-5             // measured max |Q^T Q - I| up to which first-order second passes are taken (cond(W) <~ 2e5; each pass
+                                         // squares the defect, the factor is then recomputed as the projection of W on the repaired Q)
 #define O5_POLISH_TRUST 1.0e-9           // ... below which one pass is trusted without measuring again (it leaves O(64 E^2) <= 1e-16)
 #define O5_IMG(k, i) ((k) * 64 + ((i) ^ ((((k) & 1) << 4) | ((((k) >> 1) & 3) << 2))))      // element (row i, column k) of a 64 x 64 image
 #define O5_BUF 4096
@@ -96,6 +95,25 @@ __device__ __forceinline__ void o5_gram_add(const mfma_acc_t (&T)[4], int nat, l
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)         // element (row = 16 ta + lk + 4 reg, column = 16 tb + li)
                 __hip_atomic_fetch_add(G + O5_IMG(16 * tb + li, 16 * ta + lk + 4 * reg), g[reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+}
+
+// the wave's share of M = Qa^T Qb (64 x 64, all sixteen tiles) added into the image as element (row aq of Qa's columns, column aw of
+// Qb's): both operands are the accumulator tiles themselves (a tile is a valid MFMA operand for a product contracting over its rows)
+template <bool FULL>
+__device__ __forceinline__ void o5_cross_add(const mfma_acc_t (&Qa)[4], const mfma_acc_t (&Qb)[4], int nat, lds_f64* M) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+            if (!FULL && (ta >= nat || tb >= nat)) continue;
+            mfma_acc_t g = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g = __builtin_amdgcn_mfma_f64_16x16x4f64(Qa[ta][r], Qb[tb][r], g, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)         // g[reg] = M[row = 16 ta + lk + 4 reg][column = 16 tb + li]
+                __hip_atomic_fetch_add(M + O5_IMG(16 * tb + li, 16 * ta + lk + 4 * reg), g[reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 }
 
@@ -350,8 +368,8 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
         const bool recheck = devmax > O5_POLISH_TRUST;
         // ---- moderately conditioned site (the first tall site behind the square ramp sites: cond ~ 150, eps cond^2 ~ 4e-12): one
         //      first-order pass of Cholesky-QR2.  Q^T Q = I + E = L2 L2^T with L2 = I + T + O(E^2), T = strict_lower(E) + diag(E) / 2:
-        //      Q2 = Q (I - T)^T and L = L1 (I + T) are the second pass to O(E^2) <= 1e-18 — no second factorisation, one more
-        //      triangular product.  The image holds C = Q^T Q (lower part): it becomes X2 = I - T, then L1 <- 2 L1 - L1 X2. ----
+        //      Q2 = Q (I - T)^T is the second pass to O(E^2) — no second factorisation, one more triangular product.  The image holds
+        //      C = Q^T Q (lower part): it becomes X2 = I - T.  (The factor L is recomputed from the final Q after the passes.) ----
         for (int e = tid; e < 64 * 64; e += O5_WG) {
             const int i = e & 63, k = e >> 6;
             const double v = FLb[O5_IMG(k, i)];
@@ -360,23 +378,51 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
         __syncthreads();
         mfma_acc_t q2_[4];
         o5_apply<FULL>(q_, q2_, FLb, nat, tr < nbt);
+        // The factor that goes with the repaired Q: L <- L M, M = Q^T Q2 (a cross Gram of the tiles before and after the pass), i.e. the
+        // projection (Q2^T (Q L^T))^T of what the substitution solved — NOT L (I + T): that product carries the O(E^2) of a first-order
+        // pass into Q L^T = W (1e-10 for a defect of 1e-5); the projection only what lies outside the span of Q2 (rounding level).
+        __syncthreads();                                                // every read of X2 is done
+        for (int e = tid; e < O5_BUF; e += O5_WG) FLb[e] = 0.0;
+        __syncthreads();
+        if (tr < nbt) o5_cross_add<FULL>(q_, q2_, nat, FLb);
 #pragma unroll
         for (int c = 0; c < 4; ++c) q_[c] = q2_[c];
-        double ln[8];
+        __syncthreads();
+        {
+            // L M, lower tiles only (the product is lower triangular up to rounding): ten tiles over the eight waves, results in registers
+            // until every wave has read L
+            mfma_acc_t lm[2];
+            int tix[2] = {wave, wave + 8};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + O5_WG * u, i = e & 63, jc = e >> 6;
-            double a = 0.0;
-            if (i >= jc) {
-                a = 2.0 * Gb[O5_IMG(jc, i)];
-                for (int k = jc; k <= i; ++k) a = fma(-Gb[O5_IMG(k, i)], FLb[O5_IMG(jc, k)], a);
+            for (int q = 0; q < 2; ++q) {
+                lm[q] = (mfma_acc_t){0.0, 0.0, 0.0, 0.0};
+                int ib = 0, base = 0;
+                while (base + ib + 1 <= tix[q] && ib < 3) { base += ib + 1; ++ib; }
+                const int jb = tix[q] - base;
+                if (tix[q] < 10 && (FULL || ib < nat)) {
+                    for (int kb = 0; kb <= ib; ++kb)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)                     // (L M)[16 ib + row][16 jb + col] += L[.][16 kb + 4 t + lk] M[16 kb + 4 t + lk][.]
+                            lm[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gb[O5_IMG(16 * kb + 4 * t + lk, 16 * ib + li)],
+                                                                         FLb[O5_IMG(16 * jb + li, 16 * kb + 4 * t + lk)], lm[q], 0, 0, 0);
+                }
             }
-            ln[u] = a;
-        }
-        __syncthreads();
+            __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = tid + O5_WG * u, i = e & 63, jc = e >> 6; if (i >= jc) Gb[O5_IMG(jc, i)] = ln[u]; }
-        __syncthreads();
+            for (int q = 0; q < 2; ++q) {
+                int ib = 0, base = 0;
+                while (base + ib + 1 <= tix[q] && ib < 3) { base += ib + 1; ++ib; }
+                const int jb = tix[q] - base;
+                if (tix[q] < 10 && (FULL || ib < nat)) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {                 // accumulator element (row = lk + 4 reg, column = li)
+                        const int i = 16 * ib + lk + 4 * reg, jc = 16 * jb + li;
+                        Gb[O5_IMG(jc, i)] = (i >= jc) ? lm[q][reg] : 0.0;
+                    }
+                }
+            }
+            __syncthreads();
+        }
         if (!recheck) break;                                            // E <= 1e-9: the pass leaves O(64 E^2) <= 1e-16, not measured again
         devmax = measure();
     }
