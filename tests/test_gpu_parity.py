@@ -433,6 +433,31 @@ def test_stateless_apply_compress_is_compress_of_apply(T, d, r, mb, seed):
     assert tt_rel_diff(to_oracle(got), ref) < 1e-9 and tt_rel_diff(to_oracle(got), to_oracle(two)) < 1e-9
 
 
+def test_orthogonalize_benchmark_trains_stay_in_the_fast_kernels(T):
+    """A guard on the dispatch, not on numbers: 128 of the benchmark's trains (d = 30, rank 64, seeds 30 ...) are all FINISHED by the
+    512-thread kernel — none is refused at its first tall site (cond 150 ... 2e3) and left to the third launch, where a single train's
+    remaining sweep costs as much as the whole batch's (seen as a bimodal 3.5 / 4.7 ms per 1024 trains while the repair bound was
+    1e-9) — and they pass the usual checks."""
+    import ctypes as C
+    d, r, B = 30, 64, 128
+    x0 = T.rand_tt((2,) * d, r, seed=30)
+    dx = T.DeviceTT((2,) * d, x0.ttv_rks, batch=B)
+    xs = [T.rand_tt((2,) * d, r, seed=30 + b) for b in range(B)]
+    for b in range(B):
+        dx.upload(b, xs[b])
+    dy = T.DeviceTT((2,) * d, x0.ttv_rks, batch=B)
+    T.device.orthogonalize(dx, 1, dy)
+    st = (C.c_int64 * 4)()
+    unfinished = []
+    for b in range(B):
+        T._lib.check(T._lib.lib().ttn_debug_ortho_state(b, st))
+        if int(st[3]) != 1:
+            unfinished.append((b, int(st[0])))
+    assert not unfinished, unfinished
+    for b in (0, 17, 127):
+        _ortho_checks(O, dy.download(b), xs[b], 1)
+
+
 def test_orthogonalize_fuzz_ragged_ranks(T):
     """Forty QTT trains with random lengths (3..16), random bond ranks in 1..64 (wide, square and tall sites in any order, ranks that
     are no multiples of anything) and random centres through the default dispatch (ramp kernel / 512-thread kernel / general route,
