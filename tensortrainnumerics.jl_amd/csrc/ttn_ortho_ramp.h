@@ -10,7 +10,8 @@
 //   * the reflector of step k lives in lane k: x_i = readlane(a[i], k) is a scalar, the rank-one update is two FMAs per row;
 //   * the R factor stays in registers for the next site's carry product  W'[2 be + s][al] = sum_ga R[be][ga] X'[s, al, ga]
 //     (again readlane scalars times per-lane 16-byte loads of X');
-//   * Q is formed in place from the stored reflectors (the dorg2r recurrence) and written as the core Y_j.
+//   * Q^T is accumulated on the fly (the same reflector, the same readlane scalars, applied to a second register array that starts as
+//     the identity) and written as the core Y_j.
 // Four waves per workgroup, one per SIMD: 1024 trains run in one round over the chip.
 #pragma once
 
@@ -33,80 +34,49 @@ __device__ __forceinline__ bool ortho_ramp_eligible(int n, int rl, int rr, int y
 // are not touched, rows from LO + CH on are below every k of the phase and need no masks).  The reflector is kept UNSCALED:
 // H = I - t u u^T, u = x - beta e_k, t = -1 / (beta u_k): the dot products with x need neither beta nor a stored copy of x — every
 // x_i is a readlane scalar used on the spot (two passes over the rows, no uniform array, no SGPR spills).
+// The same reflector is applied, in the same two passes, to B (b[], starts as the identity): after the last step B = H_{r-2} ... H_0 =
+// Q^T, lane c holding column c of Q^T = row c of Q.  The first version formed Q afterwards from the stored reflectors (the dorg2r
+// recurrence, a second sweep over k with its own readlanes, and a special case for lane k that cost a multiply per row to do
+// accurately); accumulating Q^T on the fly shares the readlanes with the factorisation and has no special lane.
 template <int ROWS, int LO, int CH>
-__device__ __forceinline__ void oramp_fwd_phase(double (&a)[ROWS], double& tauv, double& ukv, int kbeg, int kend) {
+__device__ __forceinline__ void oramp_phase(double (&a)[ROWS], double (&b)[ROWS], int kbeg, int kend) {
     const int lane = threadIdx.x & 63;
 #pragma unroll 1
     for (int kk = kbeg; kk < kend; ++kk) {
         const int k = __builtin_amdgcn_readfirstlane(kk);
-        double xk = 0.0, ak = 0.0;
-        double n0 = 0.0, n1 = 0.0, d0 = 0.0, d1 = 0.0;
+        double xk = 0.0, ak = 0.0, bk = 0.0;
+        double n0 = 0.0, n1 = 0.0, d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;
 #pragma unroll
         for (int i = LO; i < ROWS; ++i) {
             double xi = oramp_readlane(a[i], k);
             if (i < LO + CH) {
                 xk = (i == k) ? xi : xk;
                 ak = (i == k) ? a[i] : ak;
+                bk = (i == k) ? b[i] : bk;
                 xi = (i > k) ? xi : 0.0;
             }
-            if (i & 1) { n1 = fma(xi, xi, n1); d1 = fma(xi, a[i], d1); }
-            else       { n0 = fma(xi, xi, n0); d0 = fma(xi, a[i], d0); }
+            if (i & 1) { n1 = fma(xi, xi, n1); d1 = fma(xi, a[i], d1); e1 = fma(xi, b[i], e1); }
+            else       { n0 = fma(xi, xi, n0); d0 = fma(xi, a[i], d0); e0 = fma(xi, b[i], e0); }
         }
         const double nrm2 = n0 + n1;
-        if (nrm2 == 0.0) continue;                                        // H = I: the column is already in its final form (t stays 0)
+        if (nrm2 == 0.0) continue;                                        // H = I: the column is already in its final form
         const double beta = -copysign(sqrt(fma(xk, xk, nrm2)), xk);
         const double uk = xk - beta;
         const double t = -1.0 / (beta * uk);
         const bool mine = lane == k;
-        const double ts = (lane > k) ? t * fma(uk, ak, d0 + d1) : 0.0;    // (the lanes left of k hold finished columns and their reflectors)
+        const double tsa = (lane > k) ? t * fma(uk, ak, d0 + d1) : 0.0;   // (the lanes left of k hold finished columns and their reflectors)
+        const double tsb = t * fma(uk, bk, e0 + e1);
 #pragma unroll
         for (int i = LO; i < ROWS; ++i) {
             const double xi = oramp_readlane(a[i], k);
             if (i < LO + CH) {
                 const double ui = (i > k) ? xi : ((i == k) ? uk : 0.0);
-                const double u = fma(-ts, ui, a[i]);
+                const double u = fma(-tsa, ui, a[i]);
                 a[i] = (mine && i == k) ? beta : u;
+                b[i] = fma(-tsb, ui, b[i]);
             } else {
-                a[i] = fma(-ts, xi, a[i]);                                // (lane k: ts = 0, its rows below the diagonal keep u_i = x_i)
-            }
-        }
-        tauv = mine ? t : tauv;
-        ukv = mine ? uk : ukv;
-    }
-}
-
-// Q = H_0 H_1 ... in place (the dorg2r recurrence), steps k = kend - 1 .. kbeg of the phase whose rows start at LO.  Lane k turns its
-// reflector into column k (e_k - t u_k u), the lanes right of it take H_k.
-template <int ROWS, int LO, int CH>
-__device__ __forceinline__ void oramp_bwd_phase(double (&a)[ROWS], double tauv, double ukv, int kbeg, int kend, int rows) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int kk = kend - 1; kk >= kbeg; --kk) {
-        const int k = __builtin_amdgcn_readfirstlane(kk);
-        const double t = oramp_readlane(tauv, k), uk = oramp_readlane(ukv, k);
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int i = LO; i < ROWS; ++i) {
-            double xi = oramp_readlane(a[i], k);
-            if (i < LO + CH) xi = (i > k) ? xi : 0.0;
-            if (i & 1) s1 = fma(xi, a[i], s1); else s0 = fma(xi, a[i], s0);
-        }
-        const bool mine = lane == k;
-        const double w = -t * uk;
-        const double ts = (lane > k && lane < rows) ? t * (s0 + s1) : 0.0;
-        // lane k: its column becomes w x (x = the reflector it holds); the other lanes: a - ts x.  One FMA with a per-lane coefficient and a
-        // per-lane "keep" factor on the addend — NOT a + (w - 1) x in lane k: w - 1 rounds away the low bits of a small w (|u_k| large:
-        // w = -t u_k ~ 1e-2), 1e-14 relative in the column and 1e-12 in Q^T Q after a few sites (found by the ragged-rank fuzz test)
-        const double cf = mine ? w : -ts, keep = mine ? 0.0 : 1.0;
-#pragma unroll
-        for (int i = LO; i < ROWS; ++i) {
-            const double xi = oramp_readlane(a[i], k);
-            if (i < LO + CH) {
-                const double ui = (i > k) ? xi : 0.0;
-                const double u = fma(cf, ui, keep * a[i]);
-                a[i] = (i == k) ? (mine ? fma(w, uk, 1.0) : fma(-ts, uk, a[i])) : ((i > k) ? u : a[i]);
-            } else {
-                a[i] = fma(cf, xi, keep * a[i]);
+                a[i] = fma(-tsa, xi, a[i]);                               // (lane k: tsa = 0, its rows below the diagonal keep u_i = x_i)
+                b[i] = fma(-tsb, xi, b[i]);
             }
         }
     }
@@ -121,9 +91,9 @@ __device__ __forceinline__ void oramp_site(double (&Rp)[32], const double* __res
     const int rows = 2 * ynext;
     constexpr int HB = ROWS / 2;
     constexpr int CH = ROWS < 16 ? ROWS : 16;
-    double a[ROWS];
+    double a[ROWS], b[ROWS];
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) a[i] = 0.0;
+    for (int i = 0; i < ROWS; ++i) { a[i] = 0.0; b[i] = (i == lane) ? 1.0 : 0.0; }
     // ---- carry: W[2 be + s][al = lane] = sum_ga FL[ga][be] X_j[s, al, ga] ----
     {
         typedef double __attribute__((ext_vector_type(2))) d2;
@@ -142,14 +112,13 @@ __device__ __forceinline__ void oramp_site(double (&Rp)[32], const double* __res
             }
         }
     }
-    // ---- Householder steps k = 0 .. rows - 2 (the last row needs none); the reflector of step k stays in lane k below the diagonal ----
-    double tauv = 0.0, ukv = 0.0;
+    // ---- Householder steps k = 0 .. rows - 2 (the last row needs none) on W, accumulated into B = Q^T ----
     const int klast = rows - 1;
-    oramp_fwd_phase<ROWS, 0, CH>(a, tauv, ukv, 0, klast < CH ? klast : CH);
-    if constexpr (ROWS > 16) oramp_fwd_phase<ROWS, 16, CH>(a, tauv, ukv, 16, klast < 32 ? klast : 32);
+    oramp_phase<ROWS, 0, CH>(a, b, 0, klast < CH ? klast : CH);
+    if constexpr (ROWS > 16) oramp_phase<ROWS, 16, CH>(a, b, 16, klast < 32 ? klast : 32);
     if constexpr (ROWS > 32) {
-        oramp_fwd_phase<ROWS, 32, CH>(a, tauv, ukv, 32, klast < 48 ? klast : 48);
-        oramp_fwd_phase<ROWS, 48, CH>(a, tauv, ukv, 48, klast);
+        oramp_phase<ROWS, 32, CH>(a, b, 32, klast < 48 ? klast : 48);
+        oramp_phase<ROWS, 48, CH>(a, b, 48, klast);
     }
     // ---- R (rows x rl, upper trapezoid) to global memory and to the registers the next site's carry reads ----
     {
@@ -162,22 +131,12 @@ __device__ __forceinline__ void oramp_site(double (&Rp)[32], const double* __res
 #pragma unroll
         for (int i = (ROWS < 32 ? ROWS : 32); i < 32; ++i) Rp[i] = 0.0;
     }
-    // ---- Q (rows x rows) in place: columns k = rows - 1 .. 0; column c > k already holds a column of H_{k+1} ... H_{rows-2} ----
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) a[i] = (i <= lane || lane >= rows) ? ((i == lane && lane == rows - 1) ? 1.0 : 0.0) : a[i];
-    if constexpr (ROWS > 32) {
-        oramp_bwd_phase<ROWS, 48, CH>(a, tauv, ukv, 48, klast, rows);
-        oramp_bwd_phase<ROWS, 32, CH>(a, tauv, ukv, 32, klast < 48 ? klast : 48, rows);
-    }
-    if constexpr (ROWS > 16) oramp_bwd_phase<ROWS, 16, CH>(a, tauv, ukv, 16, klast < 32 ? klast : 32, rows);
-    oramp_bwd_phase<ROWS, 0, CH>(a, tauv, ukv, 0, klast < CH ? klast : CH, rows);
-    // ---- Y_j[s, al' = lane, be] = Q[2 be + s][al']: the two s of a (be, al') are one 16-byte store ----
+    // ---- Y_j[s, al', be] = Q[2 be + s][al'] = B[al'][2 be + s]: lane i = 2 be + s holds column i of B, register al' its row al' ----
     if (lane < rows) {
-        typedef double __attribute__((ext_vector_type(2))) d2;
-        d2* yg = reinterpret_cast<d2*>(Yj);
+        double* yl = Yj + (lane & 1) + 2LL * rows * (lane >> 1);
 #pragma unroll
-        for (int be = 0; be < HB; ++be)
-            if (be < ynext) yg[lane + rows * be] = (d2){a[2 * be], a[2 * be + 1]};
+        for (int al = 0; al < ROWS; ++al)
+            if (al < rows) yl[2 * al] = b[al];
     }
 }
 
