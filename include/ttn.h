@@ -243,7 +243,11 @@ int ttn_scale(double a, ttn_tt_t x, ttn_tt_t y);
 /* y_b = a[b] * x_b with one factor per train (a is HOST memory, length batch): what `(1 / sqrt(dot(u, u))) * u` needs on a
  * batch (src/solvers/euler.jl:83-85, :205-207) */
 int ttn_scale_batch(const double* a, ttn_tt_t x, ttn_tt_t y);
-/* y = orthogonalize(x; i=center)   src/tt_tools.jl:511-543 ; center is 1-based */
+/* y = orthogonalize(x; i=center)   src/tt_tools.jl:511-543 ; center is 1-based.  QTT trains of rank <= 64 take three kernels
+ * (csrc/ttn_ortho_ramp.h: one wave per train over the rank-ramp sites; csrc/ttn_ortho512.h: Cholesky-QR steps with a measured
+ * orthogonality check over the tall sites and the centre core; the 1024-thread k_orthogonalize for the left sweep and for trains the
+ * other two refuse) and the call reads one word back between them (it synchronises the library stream once); every other train
+ * class is one asynchronous launch.  TTN_ORTHO512 = 0 / 1, TTN_ORTHO_RAMP = 0, TTN_ORTHO_CHOLQR = 0 / 1 switch routes off for A/B runs. */
 int ttn_orthogonalize(ttn_tt_t x, int64_t center, ttn_tt_t y);
 
 /* ---- parity instrumentation: singular values seen by the last ttn_compress / ttn_bond_truncate --
