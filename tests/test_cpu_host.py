@@ -204,6 +204,21 @@ def test_c_abi_argument_errors_without_gpu(T):
     assert b"bad argument" in L.ttn_last_error_string()
 
 
+def test_tdvp_drivers_and_dense_kernels_fail_loudly_without_gpu(T):
+    """No CPU fallback behind the TDVP drivers or the stateless fused op: without a device they raise (this suite runs where
+    torch.cuda.is_available() is False); on a GPU box the test has nothing to say."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    x = T.rand_tt((2,) * 4, 2, seed=1)
+    with pytest.raises(T._lib.TTNError):
+        T.tdvp.tdvp(T.Delta(4), x, [0.1])
+    with pytest.raises(T._lib.TTNError):
+        T.apply_compress(T.Delta(4), x, 2)
+    L = T._lib.lib()
+    assert L.ttn_dense_qr(0, 4, 4, None, None, None) != 0 and L.ttn_dense_svd(1, 4, 4, None, None, None, None) != 0
+
+
 # ---- site-swap chains (SURVEY §8 f4): integer work of reorder is bit-exact with the oracle ----------------------------------
 def test_reorder_swap_lists_match_oracle():
     import ttn_amd as T
