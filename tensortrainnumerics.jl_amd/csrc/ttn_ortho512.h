@@ -286,7 +286,8 @@ __device__ __noinline__ int o5_step(double* lds, const double* Xj, double* Yj, c
         dm = wave_max(dm);
         if (lane == 0) misc[2] = dm;
     }
-    for (int e = tid; e < O5_BUF; e += O5_WG) FLb[e] = 0.0;
+    // (the FL image is not zeroed here: of the inverse only the diagonal 16 x 16 blocks exist since the substitution form of the
+    //  apply, and the wave that inverts a block writes its whole tile, zeros above the diagonal included)
     __syncthreads();
     const double dmax = unif64(misc[2]);
     const double dmin = 64.0 * DBL_EPSILON * dmax;
